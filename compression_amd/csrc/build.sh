@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds compression_amd/libmpc.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+out="$here/../libmpc.so"
+srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip)
+objs=()
+mkdir -p "$here/build"
+pids=()
+for s in "${srcs[@]}"; do
+  o="$here/build/${s%.hip}.o"
+  objs+=("$o")
+  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/mpc_internal.h" -nt "$o" ] || [ "$here/../../include/mpc.h" -nt "$o" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
+        -c "$here/$s" -o "$o" ${MPC_EXTRA_FLAGS:-} &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

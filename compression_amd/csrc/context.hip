@@ -1,0 +1,147 @@
+// Context management and layout / elementwise helpers of libmpc.
+#include "mpc_internal.h"
+
+extern "C" {
+
+const char *mpc_version(void) { return "libmpc 0.1 gfx950 (hand-written HIP, f32 MFMA transforms, MRS1 rANS)"; }
+
+int mpc_create(int device_id, void *stream, mpc_ctx **out) {
+    if (!out) return MPC_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return MPC_EHIP;
+    if (hipSetDevice(device_id) != hipSuccess) return MPC_EHIP;
+    mpc_ctx *c = new mpc_ctx();
+    c->device = device_id;
+    c->stream = (hipStream_t)stream;
+    c->err[0] = 0;
+    *out = c;
+    return MPC_OK;
+}
+
+int mpc_destroy(mpc_ctx *ctx) {
+    delete ctx;
+    return MPC_OK;
+}
+
+int mpc_set_stream(mpc_ctx *ctx, void *stream) {
+    if (!ctx) return MPC_EINVAL;
+    ctx->stream = (hipStream_t)stream;
+    return MPC_OK;
+}
+
+int mpc_synchronize(mpc_ctx *ctx) {
+    if (!ctx) return MPC_EINVAL;
+    MPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPC_OK;
+}
+
+const char *mpc_last_error(const mpc_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// NCHW <-> NHWC.  Small tensors at the API boundary (3-channel images, latents); one thread per
+// output element, the contiguous axis of the OUTPUT on threadIdx.x.
+// ---------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int C, int HW, int Cpad, int64_t total,
+                                    float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into [B][HW][Cpad]
+    if (i >= total) return;
+    int c = (int)(i % Cpad);
+    int64_t p = i / Cpad;
+    int64_t b = p / HW, hw = p % HW;
+    out[i] = c < C ? in[(b * C + c) * HW + hw] : 0.0f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, int C, int HW, int64_t total,
+                                    float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into [B][C][HW]
+    if (i >= total) return;
+    int64_t hw = i % HW;
+    int64_t bc = i / HW;
+    int64_t b = bc / C, c = bc % C;
+    out[i] = in[(b * HW + hw) * C + c];
+}
+
+__global__ void latent_to_symbols_kernel(const float *__restrict__ latent, int64_t n, float min_feat,
+                                         float q_intv, int max_sym, int16_t *__restrict__ sym,
+                                         int32_t *__restrict__ n_clamped) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int clamped = 0;
+    if (i < n) {
+        // ((y - min_feat) / q_intv).round().short()
+        float v = rintf(__fdiv_rn(__fsub_rn(latent[i], min_feat), q_intv));
+        int s = (int)v;
+        if (!(v >= 0.0f)) { s = 0; clamped = 1; }
+        if (v > (float)max_sym) { s = max_sym; clamped = 1; }
+        sym[i] = (int16_t)s;
+    }
+    if (n_clamped) {
+        unsigned long long m = __ballot(clamped);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_clamped, (int)__popcll(m));
+    }
+}
+
+__global__ void symbols_to_latent_kernel(const int16_t *__restrict__ sym, int64_t n, int min_feat, int q_intv,
+                                         float *__restrict__ latent) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) latent[i] = (float)((int)sym[i] * q_intv + min_feat);
+}
+
+// Double-precision sum: per-thread strided partial, wave shuffle reduce, one atomic per wave.
+__global__ void sum_f32_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)x[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+extern "C" {
+
+int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, int Cpad, float *out) {
+    MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad arguments");
+    int64_t total = (int64_t)B * H * W * Cpad;
+    nchw_to_nhwc_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(in, C, H * W, Cpad, total, out);
+    MPC_CHECK_LAUNCH(ctx, "nchw_to_nhwc");
+    return MPC_OK;
+}
+
+int mpc_nhwc_to_nchw(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, float *out) {
+    MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
+    int64_t total = (int64_t)B * H * W * C;
+    nhwc_to_nchw_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(in, C, H * W, total, out);
+    MPC_CHECK_LAUNCH(ctx, "nhwc_to_nchw");
+    return MPC_OK;
+}
+
+int mpc_latent_to_symbols(mpc_ctx *ctx, const float *latent, int64_t n, int min_feat, int q_intv,
+                          int n_sym_values, int16_t *sym, int32_t *n_clamped_dev) {
+    MPC_REQUIRE(ctx, latent && sym && n > 0 && q_intv > 0 && n_sym_values > 0 && n_sym_values <= 32767,
+                "latent_to_symbols: bad arguments");
+    if (n_clamped_dev) MPC_HIP(ctx, hipMemsetAsync(n_clamped_dev, 0, sizeof(int32_t), ctx->stream));
+    latent_to_symbols_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(
+        latent, n, (float)min_feat, (float)q_intv, n_sym_values - 1, sym, n_clamped_dev);
+    MPC_CHECK_LAUNCH(ctx, "latent_to_symbols");
+    return MPC_OK;
+}
+
+int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_feat, int q_intv, float *latent) {
+    MPC_REQUIRE(ctx, latent && sym && n > 0, "symbols_to_latent: bad arguments");
+    symbols_to_latent_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(sym, n, min_feat, q_intv, latent);
+    MPC_CHECK_LAUNCH(ctx, "symbols_to_latent");
+    return MPC_OK;
+}
+
+int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev) {
+    MPC_REQUIRE(ctx, x && out_dev && n > 0, "sum_f32: bad arguments");
+    MPC_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(double), ctx->stream));
+    int64_t blocks = mpc_cdiv(n, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    sum_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(x, n, out_dev);
+    MPC_CHECK_LAUNCH(ctx, "sum_f32");
+    return MPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,288 @@
+"""Operator layer: one Python function per libmpc entry point (include/mpc.h), with torch tensors used
+only as device-memory containers (`.data_ptr()`).  Every function enqueues HIP work on torch's current
+stream of the tensor's device.  There is no fallback: a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, MpcError, context_for, ptr
+
+c_void_p = ctypes.c_void_p
+
+
+def _dev(t: torch.Tensor, dtype=None, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise MpcError(f"{name} must live on the GPU (got {t.device}); compression_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise MpcError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise MpcError(f"{name} must be contiguous")
+    return t
+
+
+# ---- layout --------------------------------------------------------------------------------------
+def nchw_to_nhwc(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    cpad = C if cpad is None else cpad
+    out = torch.empty((B, H, W, cpad), dtype=torch.float32, device=x.device)
+    context_for(x.device).call("mpc_nchw_to_nhwc", ptr(x), B, C, H, W, cpad, ptr(out))
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float32, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    context_for(x.device).call("mpc_nhwc_to_nchw", ptr(x), B, C, H, W, ptr(out))
+    return out
+
+
+def latent_to_symbols(latent: torch.Tensor, min_feat: int, q_intv: int, n_sym_values: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (int16 symbols of latent.shape, int32[1] count of clamped values)."""
+    _dev(latent, torch.float32, "latent")
+    sym = torch.empty(latent.shape, dtype=torch.int16, device=latent.device)
+    nclamp = torch.empty(1, dtype=torch.int32, device=latent.device)
+    context_for(latent.device).call("mpc_latent_to_symbols", ptr(latent), latent.numel(), int(min_feat), int(q_intv),
+                                    int(n_sym_values), ptr(sym), ptr(nclamp))
+    return sym, nclamp
+
+
+def symbols_to_latent(sym: torch.Tensor, min_feat: int, q_intv: int) -> torch.Tensor:
+    _dev(sym, torch.int16, "sym")
+    out = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
+    context_for(sym.device).call("mpc_symbols_to_latent", ptr(sym), sym.numel(), int(min_feat), int(q_intv), ptr(out))
+    return out
+
+
+def sum_f32(x: torch.Tensor) -> torch.Tensor:
+    """Double-precision sum -> float64[1] device tensor."""
+    _dev(x, torch.float32, "x")
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    context_for(x.device).call("mpc_sum_f32", ptr(x), x.numel(), ptr(out))
+    return out
+
+
+# ---- learned CDF tables ------------------------------------------------------------------------
+def _param_array(params: Sequence[torch.Tensor], n_rows: int):
+    if len(params) != 11:
+        raise MpcError("expected 11 Bitparm tensors (h1,b1,a1,h2,b2,a2,h3,b3,a3,h4,b4)")
+    keep = []
+    arr = (c_void_p * 11)()
+    for i, t in enumerate(params):
+        t = _dev(t.detach().reshape(-1).contiguous(), torch.float32, f"params[{i}]")
+        if t.numel() != n_rows:
+            raise MpcError(f"params[{i}] has {t.numel()} elements, expected {n_rows}")
+        keep.append(t)
+        arr[i] = t.data_ptr()
+    return arr, keep
+
+
+def bitparm_cdf_table(params: Sequence[torch.Tensor], n_rows: int, first_target: float, L: int) -> torch.Tensor:
+    arr, keep = _param_array(params, n_rows)
+    dev = keep[0].device
+    out = torch.empty((n_rows, L), dtype=torch.float32, device=dev)
+    context_for(dev).call("mpc_bitparm_cdf_table", arr, n_rows, ctypes.c_float(first_target), L, ptr(out))
+    return out
+
+
+def bitparm_cdf_eval(params: Sequence[torch.Tensor], x: torch.Tensor, offset: float) -> torch.Tensor:
+    """x: [n_rows, n_per_row] -> CDF_row(x + offset)."""
+    _dev(x, torch.float32, "x")
+    n_rows, n_per_row = x.shape
+    arr, keep = _param_array(params, n_rows)
+    out = torch.empty_like(x)
+    context_for(x.device).call("mpc_bitparm_cdf_eval", arr, n_rows, ptr(x), n_per_row, ctypes.c_float(offset), ptr(out))
+    return out
+
+
+def renorm_cast_cdf(cdf: torch.Tensor, precision: int = 16, order: int = _lib.MPC_ORDER_ROUND_THEN_ADD) -> torch.Tensor:
+    _dev(cdf, torch.float32, "cdf")
+    L = cdf.shape[-1]
+    out = torch.empty(cdf.shape, dtype=torch.int16, device=cdf.device)
+    context_for(cdf.device).call("mpc_renorm_cast_cdf", ptr(cdf), cdf.numel() // L, L, precision, order, ptr(out))
+    return out
+
+
+def bits_lut(table_f: torch.Tensor, form: int = _lib.MPC_BITS_LOG2) -> torch.Tensor:
+    """table_f [K,M,L] -> code-length LUT [M, L-1, K]."""
+    _dev(table_f, torch.float32, "table_f")
+    K, M, L = table_f.shape
+    out = torch.empty((M, L - 1, K), dtype=torch.float32, device=table_f.device)
+    context_for(table_f.device).call("mpc_bits_lut", ptr(table_f), K, M, L, form, ptr(out))
+    return out
+
+
+# ---- competition / CDF rows ----------------------------------------------------------------------
+def prior_argmin(sym: torch.Tensor, lut: torch.Tensor, want_total: bool = False):
+    """sym int16 [n_loc, M]; lut [M,S,K] -> (idx int32 [n_loc], minbits fp32 [n_loc], total [K,n_loc] | None)."""
+    _dev(sym, torch.int16, "sym")
+    _dev(lut, torch.float32, "lut")
+    n_loc, M = sym.shape
+    M2, S, K = lut.shape
+    if M2 != M:
+        raise MpcError(f"LUT has {M2} channels, symbols have {M}")
+    idx = torch.empty(n_loc, dtype=torch.int32, device=sym.device)
+    minbits = torch.empty(n_loc, dtype=torch.float32, device=sym.device)
+    total = torch.empty((K, n_loc), dtype=torch.float32, device=sym.device) if want_total else None
+    context_for(sym.device).call("mpc_prior_argmin", ptr(sym), n_loc, M, K, S, ptr(lut), ptr(idx), ptr(minbits), ptr(total))
+    return idx, minbits, total
+
+
+def gather_cdf(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """table int16 [K,M,L], idx int32 [n_loc] -> int16 [n_loc, M, L]."""
+    _dev(table, torch.int16, "table")
+    _dev(idx, torch.int32, "idx")
+    K, M, L = table.shape
+    n_loc = idx.numel()
+    out = torch.empty((n_loc, M, L), dtype=torch.int16, device=table.device)
+    context_for(table.device).call("mpc_gather_cdf", ptr(table), K, M, L, ptr(idx), n_loc, ptr(out))
+    return out
+
+
+# ---- entropy coder ----------------------------------------------------------------------------
+MRS1_MAX_SYMBOLS_PER_STREAM = 65533
+MRS1_STREAM_OVERHEAD = 6          # 2-byte length + 4-byte final state
+MRS1_FIXED_HEADER = 16
+
+
+def choose_streams(n_loc: int, M: int, est_bytes: float, budget: float = 0.004, max_streams: int = 4096) -> Tuple[int, int]:
+    """(n_streams, locs_per_stream): as many streams as fit in `budget` of the estimated payload, at least
+    what the 16-bit stream-length field requires, at most one location per stream."""
+    min_streams = -(-n_loc // max(1, MRS1_MAX_SYMBOLS_PER_STREAM // M))
+    want = int(max(0.0, est_bytes * budget - MRS1_FIXED_HEADER) // MRS1_STREAM_OVERHEAD)
+    n = max(min_streams, min(want, max_streams, n_loc), 1)
+    lps = -(-n_loc // n)
+    n = -(-n_loc // lps)                 # drop streams that would be empty
+    return n, lps
+
+
+def rans_encode(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_images: int, n_streams: int,
+                locs_per_stream: int, out_stride: Optional[int] = None):
+    """table int16 [K,M,L]; idx int32 [n_images*n_loc]; sym int16 [n_images*n_loc*M].
+    -> (out uint8 [n_images, out_stride], nbytes uint64-as-int64 [n_images], status int32 [n_images])."""
+    _dev(table, torch.int16, "table"); _dev(idx, torch.int32, "idx"); _dev(sym, torch.int16, "sym")
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    if sym.numel() != idx.numel() * M:
+        raise MpcError("rans_encode: sym must hold M symbols per location")
+    if out_stride is None:
+        out_stride = MRS1_FIXED_HEADER + n_streams * MRS1_STREAM_OVERHEAD + 2 * n_loc * M
+    out_stride = (out_stride + 3) // 4 * 4
+    dev = table.device
+    ctx = context_for(dev)
+    ws_bytes = ctx.lib.mpc_rans_workspace_bytes(n_images, n_loc, M, n_streams)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((n_images, out_stride), dtype=torch.uint8, device=dev)
+    nbytes = torch.empty(n_images, dtype=torch.int64, device=dev)
+    status = torch.empty(n_images, dtype=torch.int32, device=dev)
+    ctx.call("mpc_rans_encode", ptr(table), K, M, L, ptr(idx), ptr(sym), n_images, n_loc, n_streams, locs_per_stream,
+             ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status))
+    return out, nbytes, status
+
+
+def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int,
+                n_streams: int, locs_per_stream: int):
+    """data uint8 [n_images, stride] on the device -> (sym int16 [n_images, n_loc*M], status int32 [n_images])."""
+    _dev(table, torch.int16, "table"); _dev(idx, torch.int32, "idx"); _dev(data, torch.uint8, "data")
+    _dev(nbytes, torch.int64, "nbytes")
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    dev = table.device
+    sym = torch.empty((n_images, n_loc * M), dtype=torch.int16, device=dev)
+    status = torch.empty(n_images, dtype=torch.int32, device=dev)
+    stride = data.shape[-1] if data.dim() == 2 else data.numel() // n_images
+    context_for(dev).call("mpc_rans_decode", ptr(table), K, M, L, ptr(idx), ptr(data), stride, ptr(nbytes), n_images,
+                          n_loc, n_streams, locs_per_stream, ptr(sym), ptr(status))
+    return sym, status
+
+
+# ---- hyperprior likelihoods -----------------------------------------------------------------------
+def laplace_bits_total(yhat: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
+    _dev(yhat, torch.float32, "yhat"); _dev(sigma, torch.float32, "sigma")
+    total = torch.zeros(1, dtype=torch.float64, device=yhat.device)
+    context_for(yhat.device).call("mpc_laplace_bits", ptr(yhat), ptr(sigma), yhat.numel(), None, ptr(total))
+    return total
+
+
+def prob_bits_total(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    _dev(hi, torch.float32, "hi"); _dev(lo, torch.float32, "lo")
+    total = torch.zeros(1, dtype=torch.float64, device=hi.device)
+    context_for(hi.device).call("mpc_prob_bits", ptr(hi), ptr(lo), hi.numel(), None, ptr(total))
+    return total
+
+
+def laplace_cdf_rows(sigma: torch.Tensor, first_target: float, L: int, precision: int = 16) -> torch.Tensor:
+    _dev(sigma, torch.float32, "sigma")
+    out = torch.empty((sigma.numel(), L), dtype=torch.int16, device=sigma.device)
+    context_for(sigma.device).call("mpc_laplace_cdf_rows", ptr(sigma), sigma.numel(), ctypes.c_float(first_target), L,
+                                   precision, ptr(out))
+    return out
+
+
+# ---- transform layers ----------------------------------------------------------------------------
+class ConvLayer:
+    """Owns one mpc_conv (packed weights on the device).  Built from PyTorch-layout parameter tensors."""
+
+    def __init__(self, kind: int, weight: torch.Tensor, bias: torch.Tensor, ksize: int, stride: int, act: int = 0,
+                 beta: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, in_abs: bool = False):
+        w = _dev(weight.detach().contiguous(), torch.float32, "weight")
+        b = _dev(bias.detach().contiguous(), torch.float32, "bias")
+        if kind == _lib.MPC_CONV:
+            cout, cin = w.shape[0], w.shape[1]
+        else:
+            cin, cout = w.shape[0], w.shape[1]
+        if w.shape[2] != ksize or w.shape[3] != ksize or b.numel() != cout:
+            raise MpcError(f"weight {tuple(w.shape)} / bias {tuple(b.shape)} do not match ksize {ksize}")
+        be = ga = None
+        if act in (_lib.MPC_ACT_GDN, _lib.MPC_ACT_IGDN):
+            be = _dev(beta.detach().contiguous(), torch.float32, "beta")
+            ga = _dev(gamma.detach().contiguous(), torch.float32, "gamma")
+            if be.numel() != cout or tuple(ga.shape) != (cout, cout):
+                raise MpcError("GDN parameter shapes do not match cout")
+        self.desc = ConvDesc(kind, cin, cout, ksize, stride, (ksize - 1) // 2,
+                             stride - 1 if kind == _lib.MPC_DECONV else 0, act, _lib.MPC_IN_ABS if in_abs else 0)
+        self.device = w.device
+        self.cin, self.cout, self.kind, self.stride, self.ksize = cin, cout, kind, stride, ksize
+        self.small_cout = kind == _lib.MPC_DECONV and stride == 2 and cout * 4 <= 32
+        ctx = context_for(w.device)
+        h = c_void_p()
+        ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
+        self.handle = h
+        self._lib = ctx.lib
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        ho, wo = ctypes.c_int(), ctypes.c_int()
+        self._lib.mpc_conv_out_hw(self.handle, H, W, ctypes.byref(ho), ctypes.byref(wo))
+        return ho.value, wo.value
+
+    def __call__(self, x: torch.Tensor, nchw_out: bool = False, clamp01: bool = False, round_out: bool = False,
+                 keep_unrounded: bool = True):
+        """x: NHWC [B,H,W,cin (3 channels padded to 4)].  Returns NHWC (or NCHW) output; with round_out
+        returns (unrounded | None, rounded)."""
+        _dev(x, torch.float32, "x")
+        B, H, W, C = x.shape
+        if C != (4 if self.cin <= 4 else self.cin):
+            raise MpcError(f"input has {C} channels, layer expects {self.cin}")
+        Ho, Wo = self.out_hw(H, W)
+        nchw_out = nchw_out or self.small_cout
+        shape = (B, self.cout, Ho, Wo) if nchw_out else (B, Ho, Wo, self.cout)
+        flags = (_lib.MPC_OUT_NCHW if nchw_out else 0) | (_lib.MPC_OUT_CLAMP01 if clamp01 else 0) | \
+                (_lib.MPC_OUT_ROUND if round_out else 0)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device) if (keep_unrounded or not round_out) else None
+        outr = torch.empty(shape, dtype=torch.float32, device=x.device) if round_out else None
+        context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))
+        return (out, outr) if round_out else out
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.mpc_conv_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,190 @@
+/*
+ * mpc.h -- C ABI of libmpc.so, the MI355X (gfx950) implementation of the Manypriors / JDC codec
+ * inference path.
+ *
+ * The reference (trougnouf/compression) is pure Python over PyTorch and has no FFI of its own; the
+ * native seams on its inference path are the ATen operators it calls and the third-party `torchac`
+ * extension.  Each entry point below replaces one such call site (cited as file:line relative to the
+ * reference root).  Conventions:
+ *   - every function returns 0 on success or a negative MPC_E* code; mpc_last_error(ctx) gives text;
+ *   - no C++ types, no torch types, no exceptions cross this boundary;
+ *   - all `*_dev` / unmarked data pointers are DEVICE pointers on the context's GPU unless the
+ *     parameter is documented as host memory; the caller owns every buffer it passes;
+ *   - work is enqueued on the context's HIP stream and is asynchronous unless stated otherwise;
+ *   - a context is not thread-safe; distinct contexts may be used from distinct threads.
+ *
+ * Activations are NHWC fp32 inside the library ([B][H][W][C], C contiguous).  The quantised latent
+ * in that layout IS the reference's symbol order (location-major, channel-minor,
+ * src/compression/models/manynets_compressor.py:264-269).
+ */
+#ifndef MPC_H
+#define MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpc_ctx mpc_ctx;
+typedef struct mpc_conv mpc_conv;
+
+enum {
+    MPC_OK = 0,
+    MPC_EINVAL = -1,   /* bad argument / unsupported shape */
+    MPC_EHIP = -2,     /* a HIP runtime call failed */
+    MPC_ENOMEM = -3,   /* device allocation failed or caller buffer too small */
+    MPC_EDATA = -4     /* data-dependent failure reported by a kernel (e.g. corrupt bitstream) */
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (NULL = the default stream).  Replaces the reference's implicit
+ * torch.cuda.set_device(device) (src/compression/libs/initfun.py:265-268). */
+int mpc_create(int device_id, void *stream, mpc_ctx **out);
+int mpc_destroy(mpc_ctx *ctx);
+int mpc_set_stream(mpc_ctx *ctx, void *stream);
+int mpc_synchronize(mpc_ctx *ctx);
+const char *mpc_last_error(const mpc_ctx *ctx);
+/* Library build string ("libmpc gfx950 ..."). */
+const char *mpc_version(void);
+
+/* ---- layout helpers ------------------------------------------------------------------------ */
+/* NCHW fp32 [B,C,H,W] -> NHWC [B,H,W,Cpad] (channels C..Cpad-1 zero).  The reference keeps NCHW
+ * throughout (e.g. Balle2018PT_compressor.py:98-102); this is the entry conversion. */
+int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, int Cpad, float *out);
+/* NHWC [B,H,W,C] -> NCHW [B,C,H,W]. */
+int mpc_nhwc_to_nchw(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, float *out);
+/* sym[i] = clamp(rint((latent[i] - min_feat) / q_intv), 0, n_sym_values-1) as int16;
+ * *n_clamped_dev (int32, device, may be NULL) receives the number of clamped values.
+ * manynets_compressor.py:264-269 (the reference widens its tables instead of clamping, :212-227;
+ * the caller can reproduce that from n_clamped). */
+int mpc_latent_to_symbols(mpc_ctx *ctx, const float *latent, int64_t n, int min_feat, int q_intv,
+                          int n_sym_values, int16_t *sym, int32_t *n_clamped_dev);
+/* latent[i] = sym[i] * q_intv + min_feat.  manynets_compressor.py:329-330. */
+int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_feat, int q_intv,
+                          float *latent);
+/* Double-precision sum of n floats into *out_dev (device double). Used for sum(minbits) -> bpp_feature
+ * (manynets_compressor.py:604-607, 634). */
+int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev);
+
+/* ---- learned CDF tables -------------------------------------------------------------------- */
+/* Float CDF table of a (multi-head) factorised prior evaluated at targets first_target + s, s < L:
+ * table_f[row][s], row < n_rows, with the 4-layer Bitparm chain of bitEstimator.py:136-141.
+ * params[11] = {h1,b1,a1,h2,b2,a2,h3,b3,a3,h4,b4}, each n_rows contiguous floats (the flattened
+ * [K,1,M,1,1] tensors, row = k*M + c).  manynets_compressor.py:142-152; abstract_model.py:277-284. */
+int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n_rows,
+                          float first_target, int L, float *table_f);
+/* Per-element evaluation of the same chain: out[row][i] = CDF_row(x[row][i] + offset); x is
+ * [n_rows][n_per_row].  bitEstimator.py:41-45 as used by abstract_model.py:238. */
+int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_rows,
+                         const float *x, int64_t n_per_row, float offset, float *out);
+
+#define MPC_ORDER_ROUND_THEN_ADD 0 /* torchac._renorm_cast_cdf_ (call site manynets_compressor.py:153) */
+#define MPC_ORDER_ADD_THEN_ROUND 1 /* abstract_model.py:59-73 */
+/* int16 CDF rows from float CDF rows, both rounding orders, wrap-around cast. */
+int mpc_renorm_cast_cdf(mpc_ctx *ctx, const float *cdf, int64_t n_rows, int L, int precision, int order,
+                        int16_t *out);
+
+#define MPC_BITS_LOG2 0 /* clamp(-log2(p + 1e-10), 0, 50)        manynets_compressor.py:551-553 */
+#define MPC_BITS_LN 1   /* clamp(-1.0*log(p + 1e-10)/log(2), 0, 50)  manynets_compressor.py:247-248 */
+/* Code-length LUT in competition layout: lut[(c*S + s)*K + k] = bits of symbol s of channel c under
+ * prior k, S = L-1, from table_f[K][M][L]. */
+int mpc_bits_lut(mpc_ctx *ctx, const float *table_f, int K, int M, int L, int form, float *lut);
+
+/* ---- prior competition --------------------------------------------------------------------- */
+/* For every location: total[k] = sum_c lut[c][sym[loc][c]][k] (channel order and fp32 association of
+ * ATen's sum over dim 2 of a [K,B,M,h,w] tensor), idx = first argmin_k, minbits = min_k.
+ * sym is [n_loc][M] int16.  total_bits (may be NULL) is [K][n_loc].
+ * manynets_compressor.py:548-554 and :238-249.  K must be 64 or less. */
+int mpc_prior_argmin(mpc_ctx *ctx, const int16_t *sym, int64_t n_loc, int M, int K, int S,
+                     const float *lut, int32_t *idx, float *minbits, float *total_bits);
+
+/* ---- per-symbol CDF rows ("CDF build") ------------------------------------------------------ */
+/* out[loc][c][:] = table[idx[loc]][c][:]   (int16 [n_loc][M][L]).  manynets_compressor.py:252-262,
+ * :317-327, :707-710.  Only parity tests and the reference-style torchac hand-off need the
+ * materialised rows; the rANS coder below reads the table directly. */
+int mpc_gather_cdf(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                   int64_t n_loc, int16_t *out);
+
+/* ---- entropy coder (replaces torchac.encode_cdf / decode_cdf, manynets_compressor.py:274,328) -- */
+/* MRS1 containers: see oracle/rans_ref.c for the byte-exact format.  A batch of n_images
+ * independent images is coded in one call; image i uses idx + i*n_loc, sym + i*n_loc*M, writes its
+ * container at out + i*out_stride and its size to nbytes_dev[i].  Each image is cut into n_streams
+ * streams of locs_per_stream locations (last stream shorter).  (locs_per_stream*M + 2) <= 65535. */
+size_t mpc_rans_workspace_bytes(int n_images, int64_t n_loc, int M, int n_streams);
+int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                    const int16_t *sym, int n_images, int64_t n_loc, int n_streams, int locs_per_stream,
+                    void *workspace, size_t workspace_bytes, uint8_t *out, size_t out_stride,
+                    uint64_t *nbytes_dev, int32_t *status_dev);
+/* Decodes n_images containers (in + i*in_stride, nbytes_dev[i] bytes; nbytes_dev is a device array)
+ * into sym_out + i*n_loc*M.  n_streams / locs_per_stream are the values the containers were written
+ * with (fields 1 and 3 of the header; every image of the batch must share them).  status_dev[i]
+ * (device int32) is 0 or a negative detail code of MPC_EDATA. */
+int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                    const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
+                    int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
+                    int32_t *status_dev);
+
+/* ---- transform layers ---------------------------------------------------------------------- */
+enum { MPC_CONV = 0, MPC_DECONV = 1 };
+enum {
+    MPC_ACT_NONE = 0,
+    MPC_ACT_GDN = 1,  /* y / sqrt(beta + gamma y^2)          GDN.py:83-91 */
+    MPC_ACT_IGDN = 2, /* y * sqrt(beta + gamma y^2) */
+    MPC_ACT_RELU = 3,
+    MPC_ACT_EXP = 4   /* SynthesisTFCodeExp_prior_net, Balle2018PT_compressor.py:248-251 */
+};
+enum {
+    MPC_IN_ABS = 1,        /* take |x| of the input (Analysis_prior_net.forward, :123-124) */
+    MPC_OUT_ROUND = 2,     /* also emit rint(out) (torch.round, manynets_compressor.py:533) */
+    MPC_OUT_CLAMP01 = 4,   /* clamp(0,1) (manynets_compressor.py:537) */
+    MPC_OUT_NCHW = 8       /* write the output as NCHW instead of NHWC */
+};
+
+typedef struct {
+    int32_t kind;     /* MPC_CONV (nn.Conv2d) or MPC_DECONV (nn.ConvTranspose2d) */
+    int32_t cin, cout;
+    int32_t ksize;    /* 3 or 5 */
+    int32_t stride;   /* 1 or 2 */
+    int32_t pad;      /* (ksize-1)/2 */
+    int32_t out_pad;  /* stride-1 for MPC_DECONV, else 0 */
+    int32_t act;      /* MPC_ACT_* applied to (conv + bias) */
+    int32_t flags;    /* MPC_IN_ABS */
+} mpc_conv_desc;
+
+/* Builds one layer from PyTorch-layout device tensors: weight [cout,cin,k,k] (MPC_CONV) or
+ * [cin,cout,k,k] (MPC_DECONV); bias [cout]; for GDN/IGDN the raw parameters beta [cout] and gamma
+ * [cout,cout] (lower bound + square reparametrisation of GDN.py:75-81 is applied here).  Weights are
+ * repacked into the MFMA operand layout in library-owned device memory.  Synchronous.
+ * Replaces nn.Conv2d / nn.ConvTranspose2d / GDN (Balle2018PT_compressor.py:82-102, :105-127,
+ * :223-251, :286-308; testolina_compressor.py:91-100). */
+int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight, const float *bias,
+                    const float *beta, const float *gamma, mpc_conv **out);
+int mpc_conv_destroy(mpc_conv *conv);
+/* Output spatial size for an input of H x W. */
+int mpc_conv_out_hw(const mpc_conv *conv, int H, int W, int *Ho, int *Wo);
+/* in: NHWC [B,H,W,cin_stride] with cin_stride = cin rounded up to a multiple of 4 (only cin = 3 is
+ * padded).  out: NHWC [B,Ho,Wo,cout] (or NCHW with MPC_OUT_NCHW).  With MPC_OUT_ROUND, `out` (may be
+ * NULL) receives the unrounded values and `out_round` the rounded ones. */
+int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const float *in, int B, int H, int W,
+                     int flags, float *out, float *out_round);
+
+/* ---- hyperprior likelihood (abstract_model.py:226-234) -------------------------------------- */
+/* bits[i] = clamp(-ln(F(y+.5) - F(y-.5) + 1e-10)/ln 2, 0, 50) with F = Laplace(0, clamp(sigma,1e-10,1e10));
+ * also accumulates the double-precision total into *total_dev (may be NULL; must be zeroed by caller).
+ * bits may be NULL. */
+int mpc_laplace_bits(mpc_ctx *ctx, const float *yhat, const float *sigma, int64_t n, float *bits,
+                     double *total_dev);
+/* Same expression on p[i] = hi[i] - lo[i] (factorised z prior, abstract_model.py:236-243). */
+int mpc_prob_bits(mpc_ctx *ctx, const float *cdf_hi, const float *cdf_lo, int64_t n, float *bits,
+                  double *total_dev);
+/* Per-element int16 CDF rows of Laplace(0, sigma[i]) at targets first_target + s (in-repo rounding
+ * order): out [n][L].  abstract_model.py:404-416. */
+int mpc_laplace_cdf_rows(mpc_ctx *ctx, const float *sigma, int64_t n, float first_target, int L,
+                         int precision, int16_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_H */

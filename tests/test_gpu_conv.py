@@ -1,0 +1,155 @@
+"""GPU parity tests of the transform layers (f32-MFMA implicit GEMM with fused GDN) against
+PyTorch-CPU fp32 convolutions, layer by layer and end to end."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import manypriors_oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from compression_amd import ops as _ops
+    return _ops
+
+
+def nhwc(x, cpad=None):
+    x = x.permute(0, 2, 3, 1).contiguous()
+    if cpad and cpad > x.shape[-1]:
+        x = F.pad(x, (0, cpad - x.shape[-1]))
+    return x
+
+
+def rel_err(got, want):
+    return ((got - want).abs().max() / want.abs().max().clamp_min(1e-12)).item()
+
+
+def _w(g, *shape, scale=0.05):
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [
+    (192, 192, 5, 2, (20, 28)),      # g_a conv2/conv3, h_a conv2/3
+    (192, 256, 5, 2, (12, 20)),      # g_a conv4 (two cout groups)
+    (256, 192, 3, 1, (7, 9)),        # h_a conv1
+    (192, 192, 5, 1, (9, 6)),        # Testolina conv
+    (64, 128, 5, 2, (17, 13)),       # odd sizes, other channel counts
+])
+def test_conv2d_plain(dev, ops, cin, cout, k, stride, hw):
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w, b = _w(g, cout, cin, k, k), _w(g, cout)
+    want = F.conv2d(x, w, b, stride=stride, padding=(k - 1) // 2)
+    layer = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), k, stride)
+    got = layer(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [
+    (256, 192, 5, 2, (6, 9)),        # g_s deconv1
+    (192, 192, 5, 2, (11, 7)),       # g_s deconv2/3, h_s deconv1/2
+    (192, 256, 3, 1, (8, 12)),       # h_s deconv3
+])
+def test_conv_transpose2d_plain(dev, ops, cin, cout, k, stride, hw):
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(cin * 3 + cout + k)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w, b = _w(g, cin, cout, k, k), _w(g, cout)
+    want = F.conv_transpose2d(x, w, b, stride=stride, padding=(k - 1) // 2, output_padding=stride - 1)
+    layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), k, stride)
+    got = layer(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 2e-6
+
+
+def test_first_layer_rgb_with_gdn(dev, ops):
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 34, 50, generator=g)
+    w, b = _w(g, 192, 3, 5, 5, scale=0.3), _w(g, 192)
+    beta, gamma = synth._gdn(g, 192)
+    want = O.gdn(F.conv2d(x, w, b, stride=2, padding=2), beta, gamma, inverse=False)
+    layer = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_GDN, beta.to(dev), gamma.to(dev))
+    got = layer(ops.nchw_to_nhwc(x.to(dev), 4)).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, want) < 3e-6
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_gdn_uses_gamma_rows_not_columns(dev, ops, inverse):
+    """gamma is deliberately asymmetric: a transposed channel mix fails this test."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 192, 10, 14, generator=g)
+    beta = 1.0 + torch.rand(192, generator=g)
+    gamma = 0.3 * torch.rand(192, 192, generator=g) * (torch.arange(192).view(-1, 1) / 192.0 + 0.1)
+    if inverse:
+        w, b = _w(g, 192, 192, 5, 5), _w(g, 192)
+        pre = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+        kind, act = _lib.MPC_DECONV, _lib.MPC_ACT_IGDN
+    else:
+        w, b = _w(g, 192, 192, 5, 5), _w(g, 192)
+        pre = F.conv2d(x, w, b, stride=2, padding=2)
+        kind, act = _lib.MPC_CONV, _lib.MPC_ACT_GDN
+    want = O.gdn(pre, beta, gamma, inverse=inverse)
+    layer = ops.ConvLayer(kind, w.to(dev), b.to(dev), 5, 2, act, beta.to(dev), gamma.to(dev))
+    got = layer(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, want) < 3e-6
+    wrong = O.gdn(pre, beta, gamma.t().contiguous(), inverse=inverse)
+    assert rel_err(wrong, want) > 1e-2
+
+
+def test_last_layer_to_rgb_nchw_clamped(dev, ops):
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 192, 9, 13, generator=g)
+    w, b = _w(g, 192, 3, 5, 5, scale=0.02), _w(g, 3, scale=0.5)
+    want = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+    layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2)
+    got = layer(nhwc(x).to(dev)).cpu()
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 2e-6
+    got_c = layer(nhwc(x).to(dev), clamp01=True).cpu()
+    assert torch.allclose(got_c, want.clamp(0, 1), atol=1e-5)
+
+
+def test_relu_exp_abs_round_and_nchw_variants(dev, ops):
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 256, 6, 8, generator=g)
+    w, b = _w(g, 192, 256, 3, 3), _w(g, 192)
+    want = F.relu(F.conv2d(x.abs(), w, b, padding=1))
+    layer = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 3, 1, _lib.MPC_ACT_RELU, in_abs=True)
+    assert rel_err(layer(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2), want) < 2e-6
+    x2 = torch.randn(1, 192, 6, 8, generator=g)
+    w2, b2 = _w(g, 192, 256, 3, 3, scale=0.02), _w(g, 256)
+    want2 = torch.exp(F.conv_transpose2d(x2, w2, b2, stride=1, padding=1))
+    layer2 = ops.ConvLayer(_lib.MPC_DECONV, w2.to(dev), b2.to(dev), 3, 1, _lib.MPC_ACT_EXP)
+    assert rel_err(layer2(nhwc(x2).to(dev)).cpu().permute(0, 3, 1, 2), want2) < 3e-6
+    w3, b3 = _w(g, 256, 192, 5, 5, scale=0.2), _w(g, 256)
+    want3 = F.conv2d(x2, w3, b3, stride=2, padding=2)
+    layer3 = ops.ConvLayer(_lib.MPC_CONV, w3.to(dev), b3.to(dev), 5, 2)
+    y, yr = layer3(nhwc(x2).to(dev), round_out=True, nchw_out=True)
+    assert rel_err(y.cpu(), want3) < 2e-6
+    assert torch.equal(yr.cpu(), torch.round(y.cpu()))
+
+
+def test_layer_create_rejects_unsupported_shapes(dev, ops):
+    from compression_amd import _lib
+    w, b = torch.zeros(100, 192, 5, 5, device=dev), torch.zeros(100, device=dev)
+    with pytest.raises(_lib.MpcError):
+        ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2)
+    with pytest.raises(_lib.MpcError):
+        ops.ConvLayer(_lib.MPC_CONV, torch.zeros(192, 192, 5, 5), torch.zeros(192), 5, 2)     # CPU tensors
