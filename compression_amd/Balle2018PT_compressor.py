@@ -1,0 +1,169 @@
+"""Transform networks (mirror of src/compression/models/Balle2018PT_compressor.py).
+
+Each network owns nn.Conv2d / nn.ConvTranspose2d / GDN modules purely as PARAMETER HOLDERS with the
+reference's attribute names, shapes and initialisation, so `state_dict()` is interchangeable with the
+reference's.  `forward` never calls them: it runs the fused libmpc layers (implicit-GEMM convolution +
+bias + GDN/IGDN/ReLU/exp epilogue) on NHWC activations.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .GDN import GDN
+
+
+def _xavier(mod, gain):
+    torch.nn.init.xavier_normal_(mod.weight.data, gain)
+    torch.nn.init.constant_(mod.bias.data, 0.01)
+    return mod
+
+
+class _FusedNet(nn.Module):
+    """Caches the packed libmpc layers and rebuilds them when a parameter changes."""
+
+    def _spec(self):
+        """-> list of (kind, conv_module, stride, act, gdn_module|None, in_abs)."""
+        raise NotImplementedError
+
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
+
+    def layers(self):
+        fp = self._fingerprint()
+        if getattr(self, "_fused_fp", None) != fp:
+            built = []
+            for kind, conv, stride, act, gdn, in_abs in self._spec():
+                built.append(ops.ConvLayer(kind, conv.weight.data, conv.bias.data, conv.kernel_size[0], stride, act,
+                                           None if gdn is None else gdn.beta.data,
+                                           None if gdn is None else gdn.gamma.data, in_abs))
+            object.__setattr__(self, "_fused", built)
+            object.__setattr__(self, "_fused_fp", fp)
+        return self._fused
+
+    def _apply(self, fn, *args, **kwargs):
+        object.__setattr__(self, "_fused_fp", None)
+        return super()._apply(fn, *args, **kwargs)
+
+
+def _check_activation(name):
+    if name != "GDN":
+        raise NotImplementedError(f"activation_function={name}: the MI355X path implements the GDN transforms")
+
+
+class Analysis_net(_FusedNet):
+    """g_a: 4 x conv 5x5 s2, GDN after the first three (Balle2018PT_compressor.py:58-102)."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320, activation_function="GDN"):
+        super().__init__()
+        _check_activation(activation_function)
+        N, M = out_channel_N, out_channel_M
+        self.gdn1, self.gdn2, self.gdn3 = GDN(N), GDN(N), GDN(N)
+        self.conv1 = _xavier(nn.Conv2d(3, N, 5, stride=2, padding=2), math.sqrt(2 * (3 + N) / 6))
+        self.conv2 = _xavier(nn.Conv2d(N, N, 5, stride=2, padding=2), math.sqrt(2))
+        self.conv3 = _xavier(nn.Conv2d(N, N, 5, stride=2, padding=2), math.sqrt(2))
+        self.conv4 = _xavier(nn.Conv2d(N, M, 5, stride=2, padding=2), math.sqrt(2 * (M + N) / (N + N)))
+
+    def _spec(self):
+        C, G = _lib.MPC_CONV, _lib.MPC_ACT_GDN
+        return [(C, self.conv1, 2, G, self.gdn1, False), (C, self.conv2, 2, G, self.gdn2, False),
+                (C, self.conv3, 2, G, self.gdn3, False), (C, self.conv4, 2, _lib.MPC_ACT_NONE, None, False)]
+
+    def forward_nhwc(self, x4, round_out=False, keep_unrounded=True):
+        """x4: NHWC image padded to 4 channels -> latent NHWC (or (y | None, round(y)))."""
+        l1, l2, l3, l4 = self.layers()
+        t = l3(l2(l1(x4)))
+        return l4(t, round_out=round_out, keep_unrounded=keep_unrounded)
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous(), 4)))
+
+
+class Synthesis_net(_FusedNet):
+    """g_s: 4 x deconv 5x5 s2, IGDN after the first three (Balle2018PT_compressor.py:262-308)."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320, out_channel_fin=3, activation_function="GDN"):
+        super().__init__()
+        _check_activation(activation_function)
+        N, M = out_channel_N, out_channel_M
+        self.igdn1, self.igdn2, self.igdn3 = GDN(N, inverse=True), GDN(N, inverse=True), GDN(N, inverse=True)
+        dc = lambda i, o: nn.ConvTranspose2d(i, o, 5, stride=2, padding=2, output_padding=1)
+        self.deconv1 = _xavier(dc(M, N), math.sqrt(2 * (M + N) / (M + M)))
+        self.deconv2 = _xavier(dc(N, N), math.sqrt(2))
+        self.deconv3 = _xavier(dc(N, N), math.sqrt(2))
+        self.deconv4 = _xavier(dc(N, out_channel_fin), math.sqrt(2 * (N + 3) / (N + N)))
+
+    def _spec(self):
+        D, G = _lib.MPC_DECONV, _lib.MPC_ACT_IGDN
+        return [(D, self.deconv1, 2, G, self.igdn1, False), (D, self.deconv2, 2, G, self.igdn2, False),
+                (D, self.deconv3, 2, G, self.igdn3, False), (D, self.deconv4, 2, _lib.MPC_ACT_NONE, None, False)]
+
+    def forward_nhwc(self, y):
+        """y: NHWC latent -> NCHW image (unclamped)."""
+        l1, l2, l3, l4 = self.layers()
+        return l4(l3(l2(l1(y))), nchw_out=True)
+
+    def forward(self, x):
+        return self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous()))
+
+
+class Analysis_prior_net(_FusedNet):
+    """h_a: |y| -> conv3 s1 + ReLU -> conv5 s2 + ReLU -> conv5 s2 (Balle2018PT_compressor.py:105-127)."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320):
+        super().__init__()
+        N, M = out_channel_N, out_channel_M
+        self.conv1 = _xavier(nn.Conv2d(M, N, 3, stride=1, padding=1), math.sqrt(2 * (M + N) / (M + M)))
+        self.conv2 = _xavier(nn.Conv2d(N, N, 5, stride=2, padding=2), math.sqrt(2))
+        self.conv3 = _xavier(nn.Conv2d(N, N, 5, stride=2, padding=2), math.sqrt(2))
+
+    def _spec(self):
+        C, R = _lib.MPC_CONV, _lib.MPC_ACT_RELU
+        return [(C, self.conv1, 1, R, None, True), (C, self.conv2, 2, R, None, False),
+                (C, self.conv3, 2, _lib.MPC_ACT_NONE, None, False)]
+
+    def forward_nhwc(self, y, round_out=False):
+        l1, l2, l3 = self.layers()
+        return l3(l2(l1(y)), round_out=round_out)
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous())))
+
+
+class SynthesisTFCodeExp_prior_net(_FusedNet):
+    """h_s: deconv5 s2 + ReLU -> deconv5 s2 + ReLU -> deconv3 s1 -> exp (Balle2018PT_compressor.py:223-251)."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320):
+        super().__init__()
+        N, M = out_channel_N, out_channel_M
+        self.deconv1 = _xavier(nn.ConvTranspose2d(N, N, 5, stride=2, padding=2, output_padding=1), math.sqrt(2))
+        self.deconv2 = _xavier(nn.ConvTranspose2d(N, N, 5, stride=2, padding=2, output_padding=1), math.sqrt(2))
+        self.deconv3 = _xavier(nn.ConvTranspose2d(N, M, 3, stride=1, padding=1), math.sqrt(2 * (M + N) / (N + N)))
+
+    def _spec(self):
+        D, R = _lib.MPC_DECONV, _lib.MPC_ACT_RELU
+        return [(D, self.deconv1, 2, R, None, False), (D, self.deconv2, 2, R, None, False),
+                (D, self.deconv3, 1, _lib.MPC_ACT_EXP, None, False)]
+
+    def forward_nhwc(self, z):
+        l1, l2, l3 = self.layers()
+        return l3(l2(l1(z)))
+
+    def forward(self, x):
+        return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous())))
+
+
+from . import abstract_model  # noqa: E402  (abstract_model does not import this module)
+
+
+class Balle2018PTTFExp_ImageCompressor(abstract_model.AbstractHyperpriorImageCompressor):
+    """The hyperprior baseline the reference actually uses (Balle2018PT_compressor.py:10-19)."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320, lossf="mse", device="cuda:0", entropy_coding=False, **kwargs):
+        super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, lossf=lossf, device=device,
+                         entropy_coding=entropy_coding, **kwargs)
+        self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.Decoder = Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.priorDecoder = SynthesisTFCodeExp_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.priorEncoder = Analysis_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)

@@ -43,8 +43,9 @@ SIGNATURES = {
     "mpc_latent_to_symbols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_symbols_to_latent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mpc_sum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpc_clamp_sse": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mpc_bitparm_cdf_table": (c_int, [c_void_p, POINTER(c_void_p), c_int64, c_float, c_int, c_void_p]),
-    "mpc_bitparm_cdf_eval": (c_int, [c_void_p, POINTER(c_void_p), c_int64, c_void_p, c_int64, c_float, c_void_p]),
+    "mpc_bitparm_cdf_eval": (c_int, [c_void_p, POINTER(c_void_p), c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "mpc_renorm_cast_cdf": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "mpc_bits_lut": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mpc_prior_argmin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,136 @@
+"""Base classes of the codec models (mirror of src/compression/models/abstract_model.py).
+
+Inference only: `forward`, `encode`, `decode`, `compress`, `update_entropy_table` run on the MI355X
+through libmpc.  Training-mode forward (noise quantisation, straight-through rounding) is outside this
+package and raises.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .bitEstimator import BitEstimator
+
+
+def _renorm_cast_cdf_(cdf, precision):
+    """Float CDF [..., L] -> int16 CDF, "add arange, then round" order (abstract_model.py:59-73)."""
+    return ops.renorm_cast_cdf(cdf.contiguous(), precision, _lib.MPC_ORDER_ADD_THEN_ROUND)
+
+
+def _scalar(v, device):
+    return torch.tensor(float(v), dtype=torch.float32, device=device)
+
+
+class AbstractImageCompressor(nn.Module):
+    def __init__(self, device):
+        super().__init__()
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+
+    def forward(self, input_image):
+        """(b,c,h,w) image batch -> dict with "reconstructed_image", "visual_loss", "bpp", and optionally
+        "bpp_feature", "bpp_sidestring" (abstract_model.py:39-48)."""
+        raise NotImplementedError
+
+    def cpu(self):
+        raise _lib.MpcError("compression_amd models run on the MI355X only; there is no CPU path")
+
+    def todev(self, device):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        return self.to(self.device)
+
+
+class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
+    """Hyperprior codec (abstract_model.py:76-272): g_a/g_s, h_a/h_s, Laplace(0, sigma) conditional for y,
+    learned factorised prior for z."""
+
+    def __init__(self, out_channel_N=192, out_channel_M=320, lossf="mse", device="cuda:0", min_feat=-127,
+                 max_feat=128, min_feat_gaussian=-127, max_feat_gaussian=128, q_intv=1, precision=16,
+                 entropy_coding=False, conditional_distribution="Laplace", passthrough_ae=False, **kwargs):
+        super().__init__(device=device)
+        self.entropy_coding = bool(entropy_coding)
+        self.out_channel_N, self.out_channel_M = out_channel_N, out_channel_M
+        self.bitEstimator_z = BitEstimator(out_channel_N)
+        self.lossf = lossf
+        if lossf not in ("mse", None):
+            raise NotImplementedError(f"lossf={lossf}: the MI355X path computes the MSE visual loss only")
+        self.min_feat, self.max_feat, self.q_intv, self.precision = min_feat, max_feat, q_intv, precision
+        self.min_feat_gaussian, self.max_feat_gaussian = min_feat_gaussian, max_feat_gaussian
+        if q_intv != 1:
+            raise NotImplementedError("q_intv != 1")
+        if conditional_distribution != "Laplace":
+            raise NotImplementedError(f"conditional_distribution={conditional_distribution}")
+        ntargets = int((-min_feat + max_feat) / q_intv + 1)
+        self.z_entropy_table = torch.empty(out_channel_M, ntargets, dtype=torch.short)
+        self.num_distributions = 1
+        self.passthrough_ae = passthrough_ae
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _require_eval(self):
+        if self.training:
+            raise NotImplementedError("training-mode forward is not part of the MI355X inference path; call .eval()")
+
+    def _visual_loss(self, recon, x):
+        xhat, sse = ops.clamp_sse(recon, x if self.lossf == "mse" else None)
+        loss = None if sse is None else (sse / recon.numel()).to(torch.float32).reshape(())
+        return xhat, loss
+
+    def _n_targets(self):
+        return int((-self.min_feat + self.max_feat) / self.q_intv + 2)
+
+    # ---- reference API ----------------------------------------------------------------------
+    def forward(self, input_image, **kwargs):
+        """Eval-mode rate/distortion forward (abstract_model.py:168-272)."""
+        self._require_eval()
+        x = input_image.contiguous()
+        B, _, H, W = x.shape
+        npix = B * H * W
+        y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
+        _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
+        sigma = self.priorDecoder.forward_nhwc(zhat)
+        recon = self.Decoder.forward_nhwc(yhat)
+        xhat, visual_loss = self._visual_loss(recon, x)
+        bits_y = ops.laplace_bits_total(yhat, sigma)
+        hi = self.bitEstimator_z.forward_nhwc(zhat, 0.5)
+        lo = self.bitEstimator_z.forward_nhwc(zhat, -0.5)
+        bits_z = ops.prob_bits_total(hi, lo)
+        bpp_feature = (bits_y / npix).to(torch.float32).reshape(())
+        bpp_z = (bits_z / npix).to(torch.float32).reshape(())
+        return {
+            "reconstructed_image": xhat,
+            "visual_loss": visual_loss,
+            "bpp_feature": bpp_feature,
+            "bpp_sidestring": bpp_z,
+            "bpp": bpp_feature + bpp_z,
+        }
+
+    def update_entropy_table(self):
+        """int16 CDF table of the factorised z prior, in-repo rounding order (abstract_model.py:274-291)."""
+        L = self._n_targets()
+        tf = self.bitEstimator_z.table(self.min_feat - 0.5, L)                 # [N, L]
+        self.main_targets_first, self.main_targets_n = self.min_feat_gaussian - 0.5, \
+            int((-self.min_feat_gaussian + self.max_feat_gaussian) / self.q_intv + 2)
+        self.z_entropy_table_float = self.entropy_table_float = tf
+        self.z_entropy_table = _renorm_cast_cdf_(tf, self.precision)
+        return True
+
+    def eval(self):
+        if self.entropy_coding and next(self.parameters()).is_cuda:
+            self.update_entropy_table()
+        return self.train(False)
+
+    def get_parameters(self, lr=None):
+        assert lr is not None
+        return [
+            {"params": self.Encoder.parameters(), "name": "encoder"},
+            {"params": self.Decoder.parameters(), "name": "decoder"},
+            {"params": self.priorEncoder.parameters(), "name": "prior_encoder"},
+            {"params": self.priorDecoder.parameters(), "name": "prior_decoder"},
+            {"params": self.bitEstimator_z.parameters(), "lr": lr * 10, "name": "bit_estimator"},
+        ]
+
+    def compress(self, input_image):
+        """-> (round(y), round(z)) as NCHW tensors (abstract_model.py:733-738)."""
+        y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(input_image.contiguous(), 4), round_out=True)
+        _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
+        return ops.nhwc_to_nchw(yhat), ops.nhwc_to_nchw(zhat)

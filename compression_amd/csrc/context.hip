@@ -98,7 +98,34 @@ __global__ void sum_f32_kernel(const float *__restrict__ x, int64_t n, double *_
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+__global__ void clamp_sse_kernel(const float *__restrict__ recon, const float *__restrict__ target, int64_t n,
+                                 float *__restrict__ xhat, double *__restrict__ sse) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float r = recon[i];
+        if (xhat) xhat[i] = fminf(fmaxf(r, 0.0f), 1.0f);
+        if (target) {
+            float d = r - target[i];
+            acc += (double)d * (double)d;
+        }
+    }
+    if (sse) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(sse, acc);
+    }
+}
+
 extern "C" {
+
+int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat, double *sse_dev) {
+    MPC_REQUIRE(ctx, recon && n > 0 && (xhat || (sse_dev && target)), "clamp_sse: bad arguments");
+    if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double), ctx->stream));
+    int64_t blocks = mpc_cdiv(n, 256 * 4);
+    if (blocks > 4096) blocks = 4096;
+    clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev);
+    MPC_CHECK_LAUNCH(ctx, "clamp_sse");
+    return MPC_OK;
+}
 
 int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, int Cpad, float *out) {
     MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad arguments");

@@ -61,10 +61,10 @@ __global__ void bitparm_table_kernel(const float *__restrict__ prep, int64_t n_r
 }
 
 __global__ void bitparm_eval_kernel(const float *__restrict__ prep, int64_t n_rows, const float *__restrict__ x,
-                                    int64_t n_per_row, float offset, float *__restrict__ out) {
+                                    int64_t n_per_row, int row_minor, float offset, float *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows * n_per_row) return;
-    int64_t r = i / n_per_row;
+    int64_t r = row_minor ? i % n_rows : i / n_per_row;
     out[i] = bitparm_chain(__fadd_rn(x[i], offset), prep + r * PREP);
 }
 
@@ -189,12 +189,12 @@ int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n
 }
 
 int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_rows, const float *x,
-                         int64_t n_per_row, float offset, float *out) {
+                         int64_t n_per_row, int row_minor, float offset, float *out) {
     MPC_REQUIRE(ctx, params && x && out && n_rows > 0 && n_per_row > 0, "bitparm_cdf_eval: bad arguments");
     float *prep = nullptr;
     int rc = make_prep(ctx, params, n_rows, &prep);
     if (rc) return rc;
-    bitparm_eval_kernel<<<dim3(blocks_for(n_rows * n_per_row)), dim3(256), 0, ctx->stream>>>(prep, n_rows, x, n_per_row, offset, out);
+    bitparm_eval_kernel<<<dim3(blocks_for(n_rows * n_per_row)), dim3(256), 0, ctx->stream>>>(prep, n_rows, x, n_per_row, row_minor, offset, out);
     MPC_CHECK_LAUNCH(ctx, "bitparm_eval");
     MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
     return MPC_OK;

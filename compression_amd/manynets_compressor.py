@@ -1,0 +1,245 @@
+"""Manypriors codec (mirror of src/compression/models/manynets_compressor.py): Balle-2018 transforms with
+K learned factorised priors competing at every latent location.
+
+Inference path on the MI355X:
+    x --g_a--> y --round--> yhat --+--> g_s --> x_hat
+                                   +--> symbols (yhat - min_feat, location-major / channel-minor)
+                                   +--> prior competition over a code-length LUT -> idx, bits
+                                   +--> MRS1 rANS coder over table[idx[loc], c, :]  <-> bytes
+`forward`, `encode`, `decode`, `update_entropy_table` keep the reference's signatures; `encode_batch` /
+`decode_batch` are batched additions (the reference's encode handles one image per call).
+"""
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, abstract_model, ops, pt_helpers
+from .Balle2018PT_compressor import Analysis_net, Synthesis_net
+from .bitEstimator import MultiHeadBitEstimator
+
+TRY_PNG_SIDESTRING = True      # pt_helpers.get_num_bits(try_png=...) for bpp_sidestring
+
+
+class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImageCompressor):
+    def __init__(self, out_channel_N=192, out_channel_M=320, lossf="mse", device="cuda:0", num_distributions=64,
+                 dist_patch_size=1, nchans_per_prior=None, min_feat=-127, max_feat=128, q_intv=1, precision=16,
+                 entropy_coding=False, model_param="2018", activation_function="GDN", passthrough_ae=False,
+                 encoder_cls=None, decoder_cls=None, **kwargs):
+        """Same constructor surface as the reference (manynets_compressor.py:42-62); unknown keyword
+        arguments are accepted and ignored as there."""
+        super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, lossf=lossf, device=device,
+                         min_feat=min_feat, max_feat=max_feat, q_intv=q_intv, precision=precision,
+                         entropy_coding=entropy_coding, passthrough_ae=passthrough_ae)
+        self.nchans_per_prior = out_channel_M if nchans_per_prior is None else nchans_per_prior
+        if dist_patch_size != 1 or self.nchans_per_prior != out_channel_M:
+            raise NotImplementedError("only dist_patch_size=1 with one prior index per location is implemented "
+                                      "(the other layouts are deprecated in the reference)")
+        if model_param not in ("2018", None, "None"):
+            raise NotImplementedError(f"model_param={model_param}")
+        if num_distributions > 64:
+            raise NotImplementedError("num_distributions > 64 (one wavefront lane per prior)")
+        del self.bitEstimator_z
+        if encoder_cls is not None and decoder_cls is not None:
+            self.Encoder = encoder_cls(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                       activation_function=activation_function)
+            self.Decoder = decoder_cls(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                       activation_function=activation_function)
+        else:
+            self.Encoder = Analysis_net(out_channel_N, out_channel_M, activation_function)
+            self.Decoder = Synthesis_net(out_channel_N, out_channel_M, activation_function=activation_function)
+        self.num_distributions = num_distributions
+        self.dist_patch_size = dist_patch_size
+        self.bitEstimators = MultiHeadBitEstimator(self.nchans_per_prior, nb_head=num_distributions,
+                                                   shape=("g", "bs", "ch", "h", "w"), **kwargs)
+        self.dists_last_use = np.zeros(num_distributions, dtype=int)
+        ntargets = int((-self.min_feat + self.max_feat) / self.q_intv + 1)
+        self.entropy_table = torch.zeros(num_distributions, out_channel_M, ntargets, dtype=torch.short)
+        self._tables_fp = None
+
+    # ---- tables -----------------------------------------------------------------------------
+    def update_entropy_table(self):
+        """Float CDF table [K,M,L] at the bin edges, its int16 renormalisation (torchac's rounding order) and
+        the two code-length LUTs of the competition (manynets_compressor.py:140-171)."""
+        K, M, L = self.num_distributions, self.out_channel_M, self._n_targets()
+        tf = self.bitEstimators.table(self.min_feat - 0.5, L).view(K, M, L)
+        self.entropy_table_float = tf
+        self.entropy_table = ops.renorm_cast_cdf(tf, self.precision, _lib.MPC_ORDER_ROUND_THEN_ADD)
+        self.entropy_table_cpu = self.entropy_table.cpu()
+        self._lut_log2 = ops.bits_lut(tf, _lib.MPC_BITS_LOG2)      # forward()'s expression
+        self._lut_ln = ops.bits_lut(tf, _lib.MPC_BITS_LN)          # encode()'s expression
+        self._tables_fp = self._table_fingerprint()
+        return True
+
+    def _table_fingerprint(self):
+        return (tuple((p.data_ptr(), p._version) for p in self.bitEstimators.parameters()), self.min_feat, self.max_feat)
+
+    def _ensure_tables(self):
+        if self._tables_fp != self._table_fingerprint():
+            self.update_entropy_table()
+
+    def _widen_tables(self):
+        """The reference doubles the table range when a latent falls outside it (manynets_compressor.py:212-227)."""
+        print(f"warning: latents exceed the CDF tables' range [{self.min_feat},{self.max_feat}]; doubling the range "
+              "(this increases runtime; clip the features instead if that is acceptable)")
+        self.min_feat = self.min_feat - self.max_feat
+        self.max_feat *= 2
+        self.update_entropy_table()
+
+    def eval(self):
+        """The reference rebuilds its tables here when entropy coding is on (abstract_model.py:327-330); here
+        they are rebuilt lazily at the next use, once the parameters are on the GPU (`model.eval().to(dev)`
+        is the reference harness' call order)."""
+        self._tables_fp = None
+        return self.train(False)
+
+    def get_parameters(self, lr=None):
+        assert lr is not None
+        return [
+            {"params": self.Encoder.parameters(), "name": "encoder"},
+            {"params": self.Decoder.parameters(), "name": "decoder"},
+            {"params": self.bitEstimators.parameters(), "lr": lr * 10, "name": "bit_estimator"},
+        ]
+
+    # ---- shared pieces -------------------------------------------------------------------------
+    def _analysis(self, x, keep_unrounded=False):
+        """-> (y | None, yhat) NHWC."""
+        return self.Encoder.forward_nhwc(ops.nchw_to_nhwc(x.contiguous(), 4), round_out=True,
+                                         keep_unrounded=keep_unrounded)
+
+    def _symbols(self, yhat):
+        """NHWC latent -> int16 symbols [n_loc, M]; widens the tables (like the reference) when a latent is out
+        of range."""
+        while True:
+            sym, nclamp = ops.latent_to_symbols(yhat, self.min_feat, self.q_intv, self._n_targets() - 1)
+            if int(nclamp.item()) == 0:
+                return sym.view(-1, self.out_channel_M)
+            self._widen_tables()
+
+    def _rans_geometry(self, n_loc, est_bytes_per_image):
+        return ops.choose_streams(n_loc, self.out_channel_M, est_bytes_per_image)
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def forward(self, input_image, **kwargs):
+        """Eval-mode forward: reconstruction, bit estimate from the prior competition (or the actual coded size
+        with entropy_coding), side-string cost (manynets_compressor.py:502-644)."""
+        self._require_eval()
+        self._ensure_tables()
+        x = input_image.contiguous()
+        B, _, H, W = x.shape
+        npix = B * H * W
+        _, yhat = self._analysis(x)
+        _, h, w, M = yhat.shape
+        recon = self.Decoder.forward_nhwc(yhat)
+        xhat, visual_loss = self._visual_loss(recon, x)
+        sym = self._symbols(yhat)
+        idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
+        dist_select = idx.view(B, h, w)
+        idx_cpu = dist_select.cpu()
+        used = np.unique(idx_cpu.numpy())
+        self.dists_last_use[used] = 0
+        self.dists_last_use[np.setdiff1d(np.arange(self.num_distributions), used, assume_unique=True)] += 1
+        if not self.entropy_coding:
+            total_bits_feature = ops.sum_f32(minbits).to(torch.float32).reshape(())
+        else:
+            streams, _ = self._encode_symbols(sym, idx, B, float(ops.sum_f32(minbits).item()) / 8 / B, verify=True)
+            total_bits_feature = torch.tensor(float(sum(len(s) for s in streams) * 8), device=x.device)
+        bpp_sidestring = torch.tensor(pt_helpers.get_num_bits(idx_cpu, integers=True, try_png=TRY_PNG_SIDESTRING),
+                                      dtype=torch.float32, device=x.device) / npix
+        bpp_feature = total_bits_feature / npix
+        return {
+            "reconstructed_image": xhat,
+            "visual_loss": visual_loss,
+            "bpp_feature": bpp_feature,
+            "bpp_sidestring": bpp_sidestring,
+            "bpp": bpp_feature + bpp_sidestring,
+            "used_dists": used.tolist(),
+            "num_forced_dists": 0,
+        }
+
+    def _encode_symbols(self, sym, idx, n_images, est_bytes_per_image, verify=False):
+        """sym int16 [n_images*n_loc, M], idx int32 [n_images*n_loc] -> (list of MRS1 byte strings, geometry)."""
+        n_loc = idx.numel() // n_images
+        n_streams, lps = self._rans_geometry(n_loc, est_bytes_per_image)
+        out, nbytes, status = ops.rans_encode(self.entropy_table, idx.reshape(-1), sym.reshape(-1), n_images, n_streams, lps)
+        if verify:
+            dec, st = ops.rans_decode(self.entropy_table, idx.reshape(-1), out, nbytes, n_images, n_streams, lps)
+            if int(st.min().item()) < 0 or not torch.equal(dec.view(-1), sym.reshape(-1)):
+                raise RuntimeError("entropy_encode error: decoded symbols do not match")
+        st_cpu, nb = status.cpu(), nbytes.cpu().tolist()
+        if int(st_cpu.min()) < 0:
+            raise _lib.MpcError(f"rANS encoder reported {st_cpu.tolist()} (symbol outside the table or zero frequency)")
+        host = out.cpu().numpy()
+        return [host[i, :nb[i]].tobytes() for i in range(n_images)], (n_streams, lps)
+
+    def encode_batch(self, input_image, entropy_coding=True):
+        """Batched encode: -> (list of byte strings | int16 symbols [B, h*w*M], idx int32 [B, h*w], h, w)."""
+        self._ensure_tables()
+        x = input_image.contiguous()
+        B = x.shape[0]
+        _, yhat = self._analysis(x)
+        _, h, w, M = yhat.shape
+        sym = self._symbols(yhat)
+        idx, minbits, _ = ops.prior_argmin(sym, self._lut_ln)
+        if not entropy_coding:
+            return sym.view(B, -1), idx.view(B, -1), h, w
+        est = float(ops.sum_f32(minbits).item()) / 8 / B
+        streams, _ = self._encode_symbols(sym, idx, B, est)
+        return streams, idx.view(B, -1), h, w
+
+    def encode(self, input_image, entropy_coding=True, out_fpath=None):
+        """One image -> [bitstream, indices int64 [h*w,1], h, w] (manynets_compressor.py:197-290).  With
+        entropy_coding=False the first element is the int16 symbol vector instead of bytes."""
+        if input_image.shape[0] != 1:
+            raise ValueError("encode() handles one image per call like the reference; use encode_batch()")
+        streams, idx, h, w = self.encode_batch(input_image, entropy_coding)
+        indices = idx.view(-1, 1).to(torch.int64)
+        if not entropy_coding:
+            return [streams.view(-1), indices, h, w]
+        bitstream = streams[0]
+        if out_fpath is not None:
+            with open(out_fpath + ".mbs", "wb") as fp:
+                fp.write(bitstream)
+            pt_helpers.compress_png(indices.view(1, h, w).cpu().numpy(), out_fpath + ".png")
+        return [bitstream, indices, h, w]
+
+    def decode_batch(self, streams: List[bytes], idx, h: int, w: int):
+        """List of MRS1 byte strings + idx [B, h*w] -> reconstruction NCHW (unclamped)."""
+        self._ensure_tables()
+        B, M = len(streams), self.out_channel_M
+        dev = self.entropy_table.device
+        heads = [np.frombuffer(s[:16], dtype="<u4") for s in streams]
+        n_streams, sps = int(heads[0][1]), int(heads[0][3])
+        if any(int(hd[1]) != n_streams or int(hd[3]) != sps for hd in heads):
+            raise ValueError("decode_batch: all streams of a batch must share one stream geometry")
+        stride = (max(len(s) for s in streams) + 3) // 4 * 4
+        host = np.zeros((B, stride), np.uint8)
+        for i, s in enumerate(streams):
+            host[i, :len(s)] = np.frombuffer(s, np.uint8)
+        data = torch.from_numpy(host).to(dev)
+        nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64, device=dev)
+        idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
+        sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, sps // M)
+        if int(status.min().item()) < 0:
+            raise _lib.MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
+        yhat = ops.symbols_to_latent(sym.view(B, h, w, M), self.min_feat, self.q_intv)
+        return self.Decoder.forward_nhwc(yhat)
+
+    def decode(self, bitstream, in_fpath=None):
+        """Tensor latent (NCHW) -> g_s(latent); [bytes, indices, h, w] or files written by encode() ->
+        entropy-decode then g_s (manynets_compressor.py:293-332)."""
+        if isinstance(bitstream, torch.Tensor):
+            return self.Decoder(bitstream)
+        if in_fpath is not None:
+            with open(in_fpath + ".mbs", "rb") as fp:
+                data = fp.read()
+            with open(in_fpath + ".png", "rb") as fp:
+                indices = torch.from_numpy(pt_helpers.png_read_grey(fp.read()))
+            h, w = indices.shape
+        else:
+            data, indices, h, w = bitstream
+        return self.decode_batch([data], indices.reshape(1, -1), h, w)
+
+
+ManyPriors_ImageCompressor = Balle2017ManyPriors_ImageCompressor

@@ -68,6 +68,20 @@ def sum_f32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def clamp_sse(recon: torch.Tensor, target: Optional[torch.Tensor]):
+    """-> (clamp(recon,0,1), float64[1] sum of squared errors vs target | None)."""
+    _dev(recon, torch.float32, "recon")
+    xhat = torch.empty_like(recon)
+    sse = None
+    if target is not None:
+        _dev(target, torch.float32, "target")
+        if target.shape != recon.shape:
+            raise MpcError("clamp_sse: shape mismatch")
+        sse = torch.empty(1, dtype=torch.float64, device=recon.device)
+    context_for(recon.device).call("mpc_clamp_sse", ptr(recon), ptr(target), recon.numel(), ptr(xhat), ptr(sse))
+    return xhat, sse
+
+
 # ---- learned CDF tables ------------------------------------------------------------------------
 def _param_array(params: Sequence[torch.Tensor], n_rows: int):
     if len(params) != 11:
@@ -91,13 +105,18 @@ def bitparm_cdf_table(params: Sequence[torch.Tensor], n_rows: int, first_target:
     return out
 
 
-def bitparm_cdf_eval(params: Sequence[torch.Tensor], x: torch.Tensor, offset: float) -> torch.Tensor:
-    """x: [n_rows, n_per_row] -> CDF_row(x + offset)."""
+def bitparm_cdf_eval(params: Sequence[torch.Tensor], x: torch.Tensor, offset: float, row_minor: bool = False) -> torch.Tensor:
+    """CDF_row(x + offset), same shape as x.  x is [n_rows, n_per_row], or with row_minor any tensor whose
+    LAST axis is the row (channel) axis, e.g. an NHWC activation."""
     _dev(x, torch.float32, "x")
-    n_rows, n_per_row = x.shape
+    if row_minor:
+        n_rows, n_per_row = x.shape[-1], x.numel() // x.shape[-1]
+    else:
+        n_rows, n_per_row = x.shape
     arr, keep = _param_array(params, n_rows)
     out = torch.empty_like(x)
-    context_for(x.device).call("mpc_bitparm_cdf_eval", arr, n_rows, ptr(x), n_per_row, ctypes.c_float(offset), ptr(out))
+    context_for(x.device).call("mpc_bitparm_cdf_eval", arr, n_rows, ptr(x), n_per_row, int(row_minor),
+                               ctypes.c_float(offset), ptr(out))
     return out
 
 

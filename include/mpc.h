@@ -68,6 +68,12 @@ int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_f
  * (manynets_compressor.py:604-607, 634). */
 int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev);
 
+/* xhat[i] = clamp(recon[i], 0, 1) (xhat may be NULL) and *sse_dev += sum (recon[i]-target[i])^2 in double
+ * (sse_dev may be NULL; zeroed by this call).  manynets_compressor.py:537 and the MSE visual loss of
+ * :543 (F.mse_loss = sse / n). */
+int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat,
+                  double *sse_dev);
+
 /* ---- learned CDF tables -------------------------------------------------------------------- */
 /* Float CDF table of a (multi-head) factorised prior evaluated at targets first_target + s, s < L:
  * table_f[row][s], row < n_rows, with the 4-layer Bitparm chain of bitEstimator.py:136-141.
@@ -75,10 +81,11 @@ int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev);
  * [K,1,M,1,1] tensors, row = k*M + c).  manynets_compressor.py:142-152; abstract_model.py:277-284. */
 int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n_rows,
                           float first_target, int L, float *table_f);
-/* Per-element evaluation of the same chain: out[row][i] = CDF_row(x[row][i] + offset); x is
- * [n_rows][n_per_row].  bitEstimator.py:41-45 as used by abstract_model.py:238. */
+/* Per-element evaluation of the same chain: out[i] = CDF_row(i)(x[i] + offset).  x is [n_rows][n_per_row]
+ * (row_minor = 0) or [n_per_row][n_rows] (row_minor = 1: the channel-minor NHWC layout).
+ * bitEstimator.py:41-45 as used by abstract_model.py:238. */
 int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_rows,
-                         const float *x, int64_t n_per_row, float offset, float *out);
+                         const float *x, int64_t n_per_row, int row_minor, float offset, float *out);
 
 #define MPC_ORDER_ROUND_THEN_ADD 0 /* torchac._renorm_cast_cdf_ (call site manynets_compressor.py:153) */
 #define MPC_ORDER_ADD_THEN_ROUND 1 /* abstract_model.py:59-73 */
