@@ -15,6 +15,47 @@ from ._lib import ConvDesc, MpcError, context_for, ptr
 c_void_p = ctypes.c_void_p
 
 
+class Profiler:
+    """Optional per-call HIP-event timing of libmpc launches (events are recorded on torch's current
+    stream, which is the stream the kernels are enqueued on).  Used by bench.py for the roofline numbers."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, meta)
+
+    def summary(self):
+        """-> {name: {"calls", "ms", "flops", "bytes"}} (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, meta in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += meta.get("flops", 0.0)
+            d["bytes"] += meta.get("bytes", 0.0)
+        return out
+
+
+PROFILER: Optional[Profiler] = None
+
+
+class _timed:
+    def __init__(self, name, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if PROFILER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILER is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILER.records.append((self.name, self.e0, e1, self.meta))
+        return False
+
+
 def _dev(t: torch.Tensor, dtype=None, name="tensor") -> torch.Tensor:
     if not t.is_cuda:
         raise MpcError(f"{name} must live on the GPU (got {t.device}); compression_amd has no CPU path")
@@ -149,7 +190,8 @@ def prior_argmin(sym: torch.Tensor, lut: torch.Tensor, want_total: bool = False)
     idx = torch.empty(n_loc, dtype=torch.int32, device=sym.device)
     minbits = torch.empty(n_loc, dtype=torch.float32, device=sym.device)
     total = torch.empty((K, n_loc), dtype=torch.float32, device=sym.device) if want_total else None
-    context_for(sym.device).call("mpc_prior_argmin", ptr(sym), n_loc, M, K, S, ptr(lut), ptr(idx), ptr(minbits), ptr(total))
+    with _timed("prior_argmin", bytes=float(n_loc) * M * 4 * K, symbols=n_loc * M):
+        context_for(sym.device).call("mpc_prior_argmin", ptr(sym), n_loc, M, K, S, ptr(lut), ptr(idx), ptr(minbits), ptr(total))
     return idx, minbits, total
 
 
@@ -160,7 +202,8 @@ def gather_cdf(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     K, M, L = table.shape
     n_loc = idx.numel()
     out = torch.empty((n_loc, M, L), dtype=torch.int16, device=table.device)
-    context_for(table.device).call("mpc_gather_cdf", ptr(table), K, M, L, ptr(idx), n_loc, ptr(out))
+    with _timed("gather_cdf", bytes=float(n_loc) * M * L * 2):
+        context_for(table.device).call("mpc_gather_cdf", ptr(table), K, M, L, ptr(idx), n_loc, ptr(out))
     return out
 
 
@@ -200,8 +243,9 @@ def rans_encode(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_ima
     out = torch.empty((n_images, out_stride), dtype=torch.uint8, device=dev)
     nbytes = torch.empty(n_images, dtype=torch.int64, device=dev)
     status = torch.empty(n_images, dtype=torch.int32, device=dev)
-    ctx.call("mpc_rans_encode", ptr(table), K, M, L, ptr(idx), ptr(sym), n_images, n_loc, n_streams, locs_per_stream,
-             ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status))
+    with _timed("rans_encode", symbols=n_images * n_loc * M):
+        ctx.call("mpc_rans_encode", ptr(table), K, M, L, ptr(idx), ptr(sym), n_images, n_loc, n_streams, locs_per_stream,
+                 ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status))
     return out, nbytes, status
 
 
@@ -216,8 +260,9 @@ def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbyt
     sym = torch.empty((n_images, n_loc * M), dtype=torch.int16, device=dev)
     status = torch.empty(n_images, dtype=torch.int32, device=dev)
     stride = data.shape[-1] if data.dim() == 2 else data.numel() // n_images
-    context_for(dev).call("mpc_rans_decode", ptr(table), K, M, L, ptr(idx), ptr(data), stride, ptr(nbytes), n_images,
-                          n_loc, n_streams, locs_per_stream, ptr(sym), ptr(status))
+    with _timed("rans_decode", symbols=n_images * n_loc * M):
+        context_for(dev).call("mpc_rans_decode", ptr(table), K, M, L, ptr(idx), ptr(data), stride, ptr(nbytes), n_images,
+                              n_loc, n_streams, locs_per_stream, ptr(sym), ptr(status))
     return sym, status
 
 
@@ -269,6 +314,13 @@ class ConvLayer:
         self.device = w.device
         self.cin, self.cout, self.kind, self.stride, self.ksize = cin, cout, kind, stride, ksize
         self.small_cout = kind == _lib.MPC_DECONV and stride == 2 and cout * 4 <= 32
+        self.act = act
+        gdn = act in (_lib.MPC_ACT_GDN, _lib.MPC_ACT_IGDN)
+        # name of the device kernel template this layer launches (matches the rocprof kernel trace)
+        tiles = 1 if self.small_cout else cout // 32
+        nf = tiles // (2 if tiles > 6 else 1)
+        self.kernel_name = "conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false",
+                                                               2 if self.small_cout else (1 if gdn else 0))
         ctx = context_for(w.device)
         h = c_void_p()
         ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
@@ -295,8 +347,20 @@ class ConvLayer:
                 (_lib.MPC_OUT_ROUND if round_out else 0)
         out = torch.empty(shape, dtype=torch.float32, device=x.device) if (keep_unrounded or not round_out) else None
         outr = torch.empty(shape, dtype=torch.float32, device=x.device) if round_out else None
-        context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))
+        with _timed(self.kernel_name, flops=self.flops(B, H, W)):
+            context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))
         return (out, outr) if round_out else out
+
+    def flops(self, B: int, H: int, W: int) -> float:
+        """Algorithmic FLOPs of one forward: 2 per multiply-accumulate of the convolution (each real tap
+        counted once: k*k*cin*cout per output pixel of a Conv2d, per INPUT pixel of a ConvTranspose2d) plus
+        2*cout^2 per output pixel for a fused GDN/IGDN."""
+        Ho, Wo = self.out_hw(H, W)
+        base = B * (Ho * Wo if self.kind == _lib.MPC_CONV else H * W)
+        fl = 2.0 * base * self.ksize * self.ksize * self.cin * self.cout
+        if self.act in (_lib.MPC_ACT_GDN, _lib.MPC_ACT_IGDN):
+            fl += 2.0 * B * Ho * Wo * self.cout * self.cout
+        return fl
 
     def __del__(self):
         try:
