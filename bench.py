@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--data", default="rand", choices=["rand", "smooth"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=4)
+    ap.add_argument("--cpu-images", type=int, default=48)
     return ap.parse_args()
 
 

@@ -84,6 +84,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise MpcError(f"{LIB_PATH} is missing: build it with compression_amd/csrc/build.sh "
                            "(this package has no CPU fallback)")
+        # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so) and the process must end up with
+        # ONE runtime shared by torch's allocator/streams and by libmpc's kernels
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)           # AttributeError here = header/library mismatch
