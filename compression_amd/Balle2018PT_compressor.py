@@ -27,8 +27,10 @@ class _FusedNet(nn.Module):
         """-> list of (kind, conv_module, stride, act, gdn_module|None, in_abs)."""
         raise NotImplementedError
 
+    precision = "fp32"     # "fp16": fp16-operand MFMA layers with fp16 activations (synthesis transforms only)
+
     def _fingerprint(self):
-        return tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
+        return (self.precision,) + tuple((p.data_ptr(), p._version, p.device) for p in self.parameters())
 
     def layers(self):
         fp = self._fingerprint()
@@ -37,7 +39,8 @@ class _FusedNet(nn.Module):
             for kind, conv, stride, act, gdn, in_abs in self._spec():
                 built.append(ops.ConvLayer(kind, conv.weight.data, conv.bias.data, conv.kernel_size[0], stride, act,
                                            None if gdn is None else gdn.beta.data,
-                                           None if gdn is None else gdn.gamma.data, in_abs))
+                                           None if gdn is None else gdn.gamma.data, in_abs,
+                                           f16=self.precision == "fp16"))
             object.__setattr__(self, "_fused", built)
             object.__setattr__(self, "_fused_fp", fp)
         return self._fused
@@ -83,10 +86,12 @@ class Analysis_net(_FusedNet):
 class Synthesis_net(_FusedNet):
     """g_s: 4 x deconv 5x5 s2, IGDN after the first three (Balle2018PT_compressor.py:262-308)."""
 
-    def __init__(self, out_channel_N=192, out_channel_M=320, out_channel_fin=3, activation_function="GDN"):
+    def __init__(self, out_channel_N=192, out_channel_M=320, out_channel_fin=3, activation_function="GDN",
+                 precision="fp16"):
         super().__init__()
         _check_activation(activation_function)
         N, M = out_channel_N, out_channel_M
+        self.precision = precision if (N % 64 == 0 and M % 64 == 0 and N <= 192) else "fp32"
         self.igdn1, self.igdn2, self.igdn3 = GDN(N, inverse=True), GDN(N, inverse=True), GDN(N, inverse=True)
         dc = lambda i, o: nn.ConvTranspose2d(i, o, 5, stride=2, padding=2, output_padding=1)
         self.deconv1 = _xavier(dc(M, N), math.sqrt(2 * (M + N) / (M + M)))
@@ -100,8 +105,11 @@ class Synthesis_net(_FusedNet):
                 (D, self.deconv3, 2, G, self.igdn3, False), (D, self.deconv4, 2, _lib.MPC_ACT_NONE, None, False)]
 
     def forward_nhwc(self, y):
-        """y: NHWC latent -> NCHW image (unclamped)."""
+        """y: NHWC fp32 latent -> NCHW fp32 image (unclamped).  With precision "fp16" (default) the four layers
+        run on fp16-operand MFMA with fp16 activations: x_hat stays within 1e-2 of the fp32 result."""
         l1, l2, l3, l4 = self.layers()
+        if self.precision == "fp16":
+            y = ops.f32_to_f16(y)
         return l4(l3(l2(l1(y))), nchw_out=True)
 
     def forward(self, x):
@@ -164,6 +172,7 @@ class Balle2018PTTFExp_ImageCompressor(abstract_model.AbstractHyperpriorImageCom
         super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, lossf=lossf, device=device,
                          entropy_coding=entropy_coding, **kwargs)
         self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
-        self.Decoder = Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.Decoder = Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                     precision=kwargs.get("synthesis_precision", "fp16"))
         self.priorDecoder = SynthesisTFCodeExp_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
         self.priorEncoder = Analysis_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)

@@ -19,7 +19,7 @@ MPC_BITS_LOG2 = 0
 MPC_BITS_LN = 1
 MPC_CONV, MPC_DECONV = 0, 1
 MPC_ACT_NONE, MPC_ACT_GDN, MPC_ACT_IGDN, MPC_ACT_RELU, MPC_ACT_EXP = 0, 1, 2, 3, 4
-MPC_IN_ABS, MPC_OUT_ROUND, MPC_OUT_CLAMP01, MPC_OUT_NCHW = 1, 2, 4, 8
+MPC_IN_ABS, MPC_OUT_ROUND, MPC_OUT_CLAMP01, MPC_OUT_NCHW, MPC_F16 = 1, 2, 4, 8, 16
 
 
 class MpcError(RuntimeError):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "mpc_conv_destroy": (c_int, [c_void_p]),
     "mpc_conv_out_hw": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "mpc_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mpc_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpc_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_laplace_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mpc_prob_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mpc_laplace_cdf_rows": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_int, c_int, c_void_p]),

@@ -64,6 +64,7 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         self.z_entropy_table = torch.empty(out_channel_M, ntargets, dtype=torch.short)
         self.num_distributions = 1
         self.passthrough_ae = passthrough_ae
+        self._synthesis_precision = kwargs.get("synthesis_precision", None)
 
     # ---- helpers ---------------------------------------------------------------------------
     def _require_eval(self):

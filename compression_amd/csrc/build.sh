@@ -3,14 +3,14 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../libmpc.so"
-srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip)
+srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip conv_igemm_f16.hip)
 objs=()
 mkdir -p "$here/build"
 pids=()
 for s in "${srcs[@]}"; do
   o="$here/build/${s%.hip}.o"
   objs+=("$o")
-  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/mpc_internal.h" -nt "$o" ] || [ "$here/../../include/mpc.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$here/$s" -nt "$o" ] || [ "$here/mpc_internal.h" -nt "$o" ] || [ "$here/conv_common.h" -nt "$o" ] || [ "$here/../../include/mpc.h" -nt "$o" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
         -c "$here/$s" -o "$o" ${MPC_EXTRA_FLAGS:-} &
     pids+=($!)

@@ -115,7 +115,31 @@ __global__ void clamp_sse_kernel(const float *__restrict__ recon, const float *_
     }
 }
 
+__global__ void f32_to_f16_kernel(const float *__restrict__ in, int64_t n, _Float16 *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (_Float16)fminf(fmaxf(in[i], -65504.0f), 65504.0f);
+}
+
+__global__ void f16_to_f32_kernel(const _Float16 *__restrict__ in, int64_t n, float *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
 extern "C" {
+
+int mpc_f32_to_f16(mpc_ctx *ctx, const float *in, int64_t n, void *out_f16) {
+    MPC_REQUIRE(ctx, in && out_f16 && n > 0, "f32_to_f16: bad arguments");
+    f32_to_f16_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(in, n, (_Float16 *)out_f16);
+    MPC_CHECK_LAUNCH(ctx, "f32_to_f16");
+    return MPC_OK;
+}
+
+int mpc_f16_to_f32(mpc_ctx *ctx, const void *in_f16, int64_t n, float *out) {
+    MPC_REQUIRE(ctx, in_f16 && out && n > 0, "f16_to_f32: bad arguments");
+    f16_to_f32_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>((const _Float16 *)in_f16, n, out);
+    MPC_CHECK_LAUNCH(ctx, "f16_to_f32");
+    return MPC_OK;
+}
 
 int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat, double *sse_dev) {
     MPC_REQUIRE(ctx, recon && n > 0 && (xhat || (sse_dev && target)), "clamp_sse: bad arguments");

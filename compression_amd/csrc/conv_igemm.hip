@@ -25,50 +25,9 @@
 //   * activations go global -> registers directly: a lane needs 16 B of ITS pixel per 8-deep k-step,
 //     nothing is shared between lanes, and an f32 MFMA (64 cycles per 32x32x2) leaves ~1500 cycles
 //     per k-step to cover the latency, so an LDS halo tile would buy nothing here.
-#include "mpc_internal.h"
-
-#include <vector>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "conv_common.h"
 
 namespace {
-
-constexpr int MAX_TAPS = 32;
-constexpr int MAX_PHASES = 4;
-constexpr int WAVES = 4;
-constexpr int PIX_PER_BLOCK = 32 * WAVES;
-
-enum { EPI_PLAIN = 0, EPI_GDN = 1, EPI_STACKED = 2 };
-
-struct Phase {
-    int ntaps;            // real taps of this phase
-    int nchunks;          // K chunks (taps*cin/32, or ceil(taps/8) for the 4-channel input path)
-    int qy, qx;           // output parity offset
-    int64_t w_off;        // float offset of this phase's packed weights
-    int tap_off;          // offset into the tap table
-};
-
-struct Params {
-    const float *in;
-    float *out;           // activation output (may be null when only out_round is wanted)
-    float *out_round;     // rint(out) (may be null)
-    const float *wpk;
-    const float *bias;
-    const float *beta;    // effective GDN parameters
-    const float *gamma;
-    const int2 *taps;     // (dy, dx) per tap, all phases
-    int B, Hi, Wi, Cs;    // input NHWC, Cs = channel stride
-    int Hb, Wb;           // base grid
-    int64_t P;            // B*Hb*Wb
-    int sy, sx;           // src = base*s + d
-    int Ho, Wo, my, mx;   // dst = base*m + q
-    int cin_blocks;       // Cin/32 (unused for the 4-channel path)
-    int cout;             // real output channels (all groups)
-    int64_t w_group;      // float stride between the packed weights of consecutive cout groups
-    int act;              // MPC_ACT_*
-    int flags;            // MPC_IN_ABS | MPC_OUT_CLAMP01 | MPC_OUT_NCHW
-    Phase ph[MAX_PHASES];
-};
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == MPC_ACT_RELU) return fmaxf(v, 0.0f);
@@ -101,7 +60,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
         by = rem / p.Wb;
         bx = rem - by * p.Wb;
     }
-    const float *in_b = p.in + (int64_t)b * p.Hi * p.Wi * p.Cs;
+    const float *in_b = (const float *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs;
+    float *const out_f = (float *)p.out;
     const bool in_abs = (p.flags & MPC_IN_ABS) != 0;
 
     // ---- loaders ---------------------------------------------------------------------------
@@ -135,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
             }
         }
     };
-    const float4 *wsrc = (const float4 *)(p.wpk + (int64_t)blockIdx.z * p.w_group + ph.w_off);
+    const float4 *wsrc = (const float4 *)((const float *)p.wpk + (int64_t)blockIdx.z * p.w_group + ph.w_off);
     auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
         const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
 #pragma unroll
@@ -214,20 +174,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
                     float v = acc[0][r] + p.bias[co];
                     if (p.flags & MPC_OUT_CLAMP01) v = fminf(fmaxf(v, 0.0f), 1.0f);
                     int yy = by * 2 + (q >> 1), xx = bx * 2 + (q & 1);
-                    p.out[(((int64_t)b * p.cout + co) * p.Ho + yy) * p.Wo + xx] = v;
+                    out_f[(((int64_t)b * p.cout + co) * p.Ho + yy) * p.Wo + xx] = v;
                 }
             }
         }
         return;
     } else if constexpr (EPI == EPI_GDN) {
         const bool inverse = p.act == MPC_ACT_IGDN;
-        float *orow = p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
+        float *orow = out_f + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll 1
         for (int fo = 0; fo < NF; ++fo) {
             f32x16 nrm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
-            const float *grow = p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
+            const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 float4 ga[4];
@@ -287,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         int64_t a = (((int64_t)b * p.cout + c0 + t) * p.Ho + oy) * p.Wo + ox;
-                        if (p.out) p.out[a] = o[t];
+                        if (out_f) out_f[a] = o[t];
                         if (p.out_round) p.out_round[a] = orr[t];
                     }
                 } else {
-                    if (p.out) *(float4 *)(p.out + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (out_f) *(float4 *)(out_f + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
                     if (p.out_round) *(float4 *)(p.out_round + opix * p.cout + c0) = make_float4(orr[0], orr[1], orr[2], orr[3]);
                 }
             }
@@ -306,6 +266,7 @@ struct PackDesc {
     int cout_pad;         // 32 * NF: rows per cout group
     int64_t w_group;      // packed floats per cout group
     int cin4;             // first-layer path
+    int f16;              // fp16 operands: chunk = tap x 64 input channels, 8 halfs per slot
     int stacked;          // last-layer path: rows = (phase, co)
     int nphase;
     int ntaps[MAX_PHASES], nchunks[MAX_PHASES], tap_off[MAX_PHASES], qy[MAX_PHASES], qx[MAX_PHASES];
@@ -314,31 +275,33 @@ struct PackDesc {
     int2 kidx[4 * MAX_TAPS];     // (ky, kx) of the tap; stacked: unused (derived per phase)
 };
 
-// Packed image of one chunk: [k8 (4)][h (2)][cout_pad][t (4)].
-__global__ void pack_weights_kernel(const PackDesc d, const float *__restrict__ w, float *__restrict__ out,
+// Packed image of one chunk: [kstep (4)][h (2)][cout_pad][t (E)] with E = 4 floats (f32 path, chunk = 32 input
+// channels) or 8 halfs (f16 path, chunk = 64 input channels).
+__global__ void pack_weights_kernel(const PackDesc d, const float *__restrict__ w, void *__restrict__ out,
                                     int64_t total) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
+    const int E = d.f16 ? 8 : 4;
     const int group = (int)(i / d.w_group);
     const int64_t ig = i - (int64_t)group * d.w_group;
     int phase = 0;
     while (phase + 1 < d.nphase && ig >= d.w_off[phase + 1]) ++phase;
     int64_t l = ig - d.w_off[phase];
-    const int chunk_elems = d.cout_pad * 32;
+    const int chunk_elems = d.cout_pad * 8 * E;
     int chunk = (int)(l / chunk_elems);
     int r = (int)(l % chunk_elems);
-    int t = r & 3;
-    int row = (r >> 2) % d.cout_pad;
-    int kh = (r >> 2) / d.cout_pad;       // k8*2 + h
+    int t = r % E;
+    int row = (r / E) % d.cout_pad;
+    int kh = (r / E) / d.cout_pad;        // kstep*2 + h
     int k8 = kh >> 1, hh = kh & 1;
     int tap, ci;
     if (d.cin4) {
         tap = chunk * 8 + k8 * 2 + hh;
         ci = t;
     } else {
-        int cb = d.cin / 32;
+        int cb = d.cin / (8 * E);
         tap = chunk / cb;
-        ci = (chunk % cb) * 32 + k8 * 8 + hh * 4 + t;
+        ci = (chunk % cb) * 8 * E + k8 * 2 * E + hh * E + t;
     }
     float v = 0.0f;
     if (tap < d.ntaps[phase] && ci < d.cin) {
@@ -366,7 +329,19 @@ __global__ void pack_weights_kernel(const PackDesc d, const float *__restrict__ 
             v = w[src];
         }
     }
-    out[i] = v;
+    if (d.f16) ((_Float16 *)out)[i] = (_Float16)v;
+    else ((float *)out)[i] = v;
+}
+
+// fp16 gamma in the operand order of the fused GDN MFMA: out[c'][((f*2 + s)*2 + h)*8 + jj] =
+// gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
+__global__ void pack_gamma_f16_kernel(const float *__restrict__ gamma_eff, int cout, _Float16 *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cout * cout) return;
+    int cp = i / cout, r = i % cout;
+    int jj = r & 7, hh = (r >> 3) & 1, s = (r >> 4) & 1, f = r >> 5;
+    int c = 32 * f + 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+    out[i] = (_Float16)gamma_eff[(int64_t)cp * cout + c];
 }
 
 // GDN reparametrisation (src/compression/models/GDN.py:75-81): max(x, bound)^2 - pedestal
@@ -379,20 +354,6 @@ __global__ void gdn_reparam_kernel(const float *__restrict__ x, int64_t n, float
 }
 
 }  // namespace
-
-struct mpc_conv {
-    mpc_conv_desc desc;
-    int device;
-    int nf;               // accumulator tiles per wave
-    int groups;           // cout groups (grid.z)
-    int64_t w_group;      // packed floats per group
-    bool cin4, stacked;
-    int nphase;
-    int sy, sx, my, mx;
-    Phase ph[MAX_PHASES];
-    float *wpk = nullptr, *bias = nullptr, *beta = nullptr, *gamma = nullptr;
-    int2 *taps = nullptr;
-};
 
 namespace {
 
@@ -428,6 +389,11 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     MPC_REQUIRE(ctx, !gdn || (beta && gamma), "conv_create: GDN needs beta and gamma");
     const bool cin4 = d.cin <= 4;
     const bool stacked = d.kind == MPC_DECONV && d.stride == 2 && d.cout * 4 <= 32;
+    const bool f16 = (d.flags & MPC_F16) != 0;
+    MPC_REQUIRE(ctx, !f16 || (!cin4 && d.cin % 64 == 0), "conv_create: the fp16 path needs cin to be a multiple of 64");
+    MPC_REQUIRE(ctx, !f16 || (d.flags & MPC_IN_ABS) == 0, "conv_create: MPC_IN_ABS is not available on the fp16 path");
+    MPC_REQUIRE(ctx, !f16 || d.act == MPC_ACT_NONE || d.act == MPC_ACT_RELU || d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN,
+                "conv_create: the fp16 path supports no activation, ReLU, GDN and IGDN");
     MPC_REQUIRE(ctx, cin4 ? (d.kind == MPC_CONV) : (d.cin % 32 == 0), "conv_create: cin must be <= 4 (Conv2d only) or a multiple of 32");
     MPC_REQUIRE(ctx, stacked || d.cout % 32 == 0, "conv_create: cout must be a multiple of 32 (or <= 8 for a stride-2 ConvTranspose2d)");
     MPC_REQUIRE(ctx, !(stacked && d.ksize != 5), "conv_create: small-cout ConvTranspose2d needs ksize 5");
@@ -442,12 +408,13 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     MPC_REQUIRE(ctx, !(stacked && (gdn || d.act != MPC_ACT_NONE)), "conv_create: small-cout layer supports no activation");
 
     mpc_conv *c = new mpc_conv();
-    c->desc = d; c->device = ctx->device; c->nf = nf; c->groups = groups; c->cin4 = cin4; c->stacked = stacked;
+    c->desc = d; c->device = ctx->device; c->nf = nf; c->groups = groups; c->cin4 = cin4; c->stacked = stacked; c->f16 = f16;
+    MPC_REQUIRE(ctx, !f16 || groups == 1, "conv_create: the fp16 path supports cout <= 192");
 
     PackDesc pd;
     memset(&pd, 0, sizeof(pd));
     pd.kind = d.kind; pd.cin = d.cin; pd.cout = d.cout; pd.ksize = d.ksize; pd.stride = d.stride; pd.pad = d.pad;
-    pd.cout_pad = nf * 32; pd.cin4 = cin4; pd.stacked = stacked;
+    pd.cout_pad = nf * 32; pd.cin4 = cin4; pd.stacked = stacked; pd.f16 = f16;
     int ntap_total = 0;
     auto add_phase = [&](int qy, int qx) { pd.qy[pd.nphase] = qy; pd.qx[pd.nphase] = qx; pd.tap_off[pd.nphase] = ntap_total; pd.ntaps[pd.nphase] = 0; return pd.nphase++; };
     auto add_tap = [&](int ph, int dy, int dx, int ky, int kx) { pd.taps[ntap_total] = make_int2(dy, dx); pd.kidx[ntap_total] = make_int2(ky, kx); ++ntap_total; ++pd.ntaps[ph]; };
@@ -485,9 +452,9 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     c->nphase = pd.nphase;
     int64_t w_total = 0;
     for (int ph = 0; ph < pd.nphase; ++ph) {
-        pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / 32);
+        pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
         pd.w_off[ph] = w_total;
-        w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * 32;
+        w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * (f16 ? 64 : 32);
         c->ph[ph].ntaps = pd.ntaps[ph]; c->ph[ph].nchunks = pd.nchunks[ph];
         c->ph[ph].qy = pd.qy[ph]; c->ph[ph].qx = pd.qx[ph];
         c->ph[ph].w_off = pd.w_off[ph]; c->ph[ph].tap_off = pd.tap_off[ph];
@@ -503,7 +470,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         mpc_conv_destroy(c);
         return MPC_EHIP;
     };
-    if ((e = hipMalloc((void **)&c->wpk, sizeof(float) * w_total)) != hipSuccess) return fail("hipMalloc(weights)");
+    if ((e = hipMalloc((void **)&c->wpk, (f16 ? sizeof(_Float16) : sizeof(float)) * w_total)) != hipSuccess) return fail("hipMalloc(weights)");
     if ((e = hipMalloc((void **)&c->bias, sizeof(float) * nf * groups * 32)) != hipSuccess) return fail("hipMalloc(bias)");
     if ((e = hipMalloc((void **)&c->taps, sizeof(int2) * ntap_total)) != hipSuccess) return fail("hipMalloc(taps)");
     if ((e = hipMemcpyAsync(c->taps, pd.taps, sizeof(int2) * ntap_total, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy taps");
@@ -518,7 +485,15 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         if ((e = hipMalloc((void **)&c->beta, sizeof(float) * d.cout)) != hipSuccess) return fail("hipMalloc(beta)");
         if ((e = hipMalloc((void **)&c->gamma, sizeof(float) * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma)");
         gdn_reparam_kernel<<<dim3((unsigned)mpc_cdiv(d.cout, 256)), dim3(256), 0, ctx->stream>>>(beta, d.cout, beta_bound, pedestal, c->beta);
-        gdn_reparam_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>(gamma, (int64_t)d.cout * d.cout, gamma_bound, pedestal, c->gamma);
+        gdn_reparam_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>(gamma, (int64_t)d.cout * d.cout, gamma_bound, pedestal, (float *)c->gamma);
+        if (f16) {
+            void *g16 = nullptr;
+            if ((e = hipMalloc(&g16, sizeof(_Float16) * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma f16)");
+            pack_gamma_f16_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>((const float *)c->gamma, d.cout, (_Float16 *)g16);
+            if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { (void)hipFree(g16); return fail("pack gamma"); }
+            (void)hipFree(c->gamma);
+            c->gamma = g16;
+        }
         if ((e = hipGetLastError()) != hipSuccess) return fail("gdn_reparam launch");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("synchronize");
@@ -546,7 +521,7 @@ int mpc_conv_out_hw(const mpc_conv *c, int H, int W, int *Ho, int *Wo) {
     return MPC_OK;
 }
 
-int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const float *in, int B, int H, int W, int flags, float *out,
+int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
                      float *out_round) {
     MPC_REQUIRE(ctx, c && in && B > 0 && H > 0 && W > 0, "conv_forward: bad arguments");
     MPC_REQUIRE(ctx, c->device == ctx->device, "conv_forward: layer was created on another device");
@@ -574,6 +549,11 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const float *in, int B, in
 
     p.w_group = c->w_group;
     const int np = c->nphase, ng = c->groups;
+    if (c->f16) {
+        MPC_REQUIRE(ctx, !want_round && !(flags & MPC_OUT_NCHW && !c->stacked), "conv_forward: the fp16 path writes fp16 NHWC (fp32 NCHW on the small-cout layer) and has no rounding output");
+        p.cin_blocks = d.cin / 64;
+        return mpc_conv_launch_f16(ctx, p, c);
+    }
     if (c->stacked) return launch<1, false, EPI_STACKED>(ctx, p, np, ng);
     if (gdn) {
         if (c->cin4) {

@@ -1,0 +1,240 @@
+// fp16-operand / fp32-accumulate variant of the implicit-GEMM transform kernel
+// (v_mfma_f32_32x32x16_f16), used for the synthesis transform g_s, whose output only has to be within
+// 1e-2 of the fp32 reference (the analysis transform must stay on the exact f32 path: its output is
+// rounded to symbols).
+//
+// Same formulation, orientation and work decomposition as conv_igemm.hip:
+//   D[cout][pixel] += W_tap[cout][ci] * in[ci][src(pixel, tap)],   wave = 32 pixels x all Cout,
+// with a K chunk of (1 tap x 64 input channels) = 4 MFMA k-steps of 16.  Per k-step a lane holds
+// 8 consecutive input channels of ITS pixel (one 16-byte global load) and reads 8 consecutive-k
+// weights of its output channel from LDS (one ds_read_b128).  Activations are fp16 NHWC in HBM, so the
+// layer-to-layer traffic is half of the f32 path's.
+//
+// Fused GDN / IGDN: norm[c'] = beta[c'] + sum_c gamma[c'][c] * y[c]^2 is a second fp16 MFMA whose B
+// operand is built from the lane's own accumulators: registers 8s..8s+7 of tile f, squared, are the
+// 8 k-values of k-step s for this lane half, in the order  c = 32f + 16s + 8(j>>2) + 4h + (j&3);
+// gamma is stored pre-permuted in that order.  y^2 is scaled by 2^-8 and saturated before the
+// conversion to fp16 (|y| up to 4096 is represented; smaller terms that underflow are negligible
+// against beta), the scale is undone on the fp32 sum.
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float SQ_SCALE = 0.00390625f;      // 2^-8
+constexpr float SQ_UNSCALE = 256.0f;
+constexpr float HALF_MAX = 65504.0f;
+
+__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
+
+__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -HALF_MAX), HALF_MAX); }
+
+template <int NF, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) {
+    constexpr int COUT = NF * 32;
+    constexpr int CHUNK_F4 = COUT * 8;                    // 16-byte slots per weight chunk (Cout x 64 halfs)
+    constexpr int STAGE = CHUNK_F4 / 256;
+    extern __shared__ float4 lds[];                       // 2 x CHUNK_F4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const Phase ph = p.ph[blockIdx.y];
+    const int2 *taps = p.taps + ph.tap_off;
+
+    const int64_t pix = (int64_t)blockIdx.x * PIX_PER_BLOCK + wave * 32 + j;
+    const bool pvalid = pix < p.P;
+    int b = 0, by = 0, bx = 0;
+    if (pvalid) {
+        int64_t hw = (int64_t)p.Hb * p.Wb;
+        b = (int)(pix / hw);
+        int rem = (int)(pix - (int64_t)b * hw);
+        by = rem / p.Wb;
+        bx = rem - by * p.Wb;
+    }
+    const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs;
+
+    auto load_b = [&](int chunk, float4 (&dst)[4]) {
+        int tap = chunk / p.cin_blocks;
+        int cb = chunk - tap * p.cin_blocks;
+        int2 d = taps[tap];
+        int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
+        bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const _Float16 *src = in_b + ((int64_t)iy * p.Wi + ix) * p.Cs + cb * 64 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *(const float4 *)(src + 16 * ks);
+            dst[ks] = v;
+        }
+    };
+    const float4 *wsrc = (const float4 *)((const _Float16 *)p.wpk + ph.w_off);
+    auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
+        const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
+#pragma unroll
+        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * 256];
+    };
+    auto store_w = [&](int buf, const float4 (&src)[STAGE]) {
+        float4 *d = lds + buf * CHUNK_F4 + tid;
+#pragma unroll
+        for (int r = 0; r < STAGE; ++r) d[r * 256] = src[r];
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    float4 bcur[4], bnext[4], wreg[STAGE];
+    load_w(0, wreg);
+    load_b(0, bcur);
+    store_w(0, wreg);
+    __syncthreads();
+
+    const int nch = ph.nchunks;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int nxt = (ch + 1 < nch) ? ch + 1 : ch;     // unconditional prefetch keeps everything in registers
+        load_w(nxt, wreg);
+        load_b(nxt, bnext);
+        const float4 *wl = lds + (ch & 1) * CHUNK_F4 + h * COUT + j;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 bv = as_half8(bcur[ks]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const half8 av = as_half8(wl[(ks * 2) * COUT + f * 32]);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[f], 0, 0, 0);
+            }
+        }
+        store_w((ch + 1) & 1, wreg);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bcur[ks] = bnext[ks];
+    }
+
+    // ---- epilogue: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h of pixel `pix` -----------------
+    const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
+
+    if constexpr (EPI == EPI_STACKED) {
+        if (pvalid) {
+            float *out_f = (float *)p.out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                int q = row / p.cout, co = row - q * p.cout;
+                if (q < 4) {
+                    float v = acc[0][r] + p.bias[co];
+                    if (p.flags & MPC_OUT_CLAMP01) v = fminf(fmaxf(v, 0.0f), 1.0f);
+                    int yy = by * 2 + (q >> 1), xx = bx * 2 + (q & 1);
+                    out_f[(((int64_t)b * p.cout + co) * p.Ho + yy) * p.Wo + xx] = v;
+                }
+            }
+        }
+        return;
+    } else {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bb = *(const float4 *)(p.bias + 32 * f + 8 * g + 4 * h);
+                acc[f][4 * g + 0] += bb.x;
+                acc[f][4 * g + 1] += bb.y;
+                acc[f][4 * g + 2] += bb.z;
+                acc[f][4 * g + 3] += bb.w;
+            }
+        _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
+        if constexpr (EPI == EPI_GDN) {
+            const bool inverse = p.act == MPC_ACT_IGDN;
+#pragma unroll 1
+            for (int fo = 0; fo < NF; ++fo) {
+                f32x16 nrm;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
+                // permuted gamma row of output channel 32fo + j: slots [(f*2 + s)*2 + h] of 8 halfs
+                const float4 *grow = (const float4 *)((const _Float16 *)p.gamma + (int64_t)(32 * fo + j) * COUT) + h;
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const half8 av = as_half8(grow[(f * 2 + s) * 2]);
+                        half8 bv;
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            float y = acc[f][8 * s + jj];
+                            bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                        }
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, nrm, 0, 0, 0);
+                    }
+                f32x16 yv;
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    if (f == fo) yv = acc[f];
+                if (pvalid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int c0 = 32 * fo + 8 * g + 4 * h;
+                        float4 be = *(const float4 *)(p.beta + c0);
+                        const float bev[4] = {be.x, be.y, be.z, be.w};
+                        half4 o;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float n = sqrtf(nrm[4 * g + t] * SQ_UNSCALE + bev[t]);
+                            float y = yv[4 * g + t];
+                            o[t] = sat_half(inverse ? y * n : y / n);
+                        }
+                        *(half4 *)(orow + c0) = o;
+                    }
+                }
+            }
+        } else {
+            if (!pvalid) return;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int c0 = 32 * f + 8 * g + 4 * h;
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float v = acc[f][4 * g + t];
+                        if (p.act == MPC_ACT_RELU) v = fmaxf(v, 0.0f);
+                        o[t] = sat_half(v);
+                    }
+                    *(half4 *)(orow + c0) = o;
+                }
+        }
+    }
+}
+
+template <int NF, int EPI>
+int launch(mpc_ctx *ctx, const Params &p, int nphase) {
+    size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
+    auto kern = conv_igemm_f16_kernel<NF, EPI>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int64_t bx = mpc_cdiv(p.P, PIX_PER_BLOCK);
+    MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
+    kern<<<dim3((unsigned)bx, (unsigned)nphase, 1), dim3(256), lds, ctx->stream>>>(p);
+    MPC_CHECK_LAUNCH(ctx, "conv_igemm_f16");
+    return MPC_OK;
+}
+
+}  // namespace
+
+int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
+    if (c->stacked) return launch<1, EPI_STACKED>(ctx, p, c->nphase);
+    if (gdn) {
+        if (c->nf == 4) return launch<4, EPI_GDN>(ctx, p, c->nphase);
+        if (c->nf == 6) return launch<6, EPI_GDN>(ctx, p, c->nphase);
+    } else {
+        if (c->nf == 4) return launch<4, EPI_PLAIN>(ctx, p, c->nphase);
+        if (c->nf == 6) return launch<6, EPI_PLAIN>(ctx, p, c->nphase);
+    }
+    MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16): unsupported layer shape (cout/32 = %d)", c->nf);
+}

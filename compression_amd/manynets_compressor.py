@@ -49,6 +49,10 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         else:
             self.Encoder = Analysis_net(out_channel_N, out_channel_M, activation_function)
             self.Decoder = Synthesis_net(out_channel_N, out_channel_M, activation_function=activation_function)
+        # "fp16" (default): g_s on fp16-operand MFMA, x_hat within 1e-2 of fp32; "fp32": exact f32 MFMA
+        sp = kwargs.pop("synthesis_precision", None)
+        if sp is not None:
+            self.Decoder.precision = sp
         self.num_distributions = num_distributions
         self.dist_patch_size = dist_patch_size
         self.bitEstimators = MultiHeadBitEstimator(self.nchans_per_prior, nb_head=num_distributions,

@@ -101,6 +101,20 @@ def symbols_to_latent(sym: torch.Tensor, min_feat: int, q_intv: int) -> torch.Te
     return out
 
 
+def f32_to_f16(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    context_for(x.device).call("mpc_f32_to_f16", ptr(x), x.numel(), ptr(out))
+    return out
+
+
+def f16_to_f32(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, torch.float16, "x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    context_for(x.device).call("mpc_f16_to_f32", ptr(x), x.numel(), ptr(out))
+    return out
+
+
 def sum_f32(x: torch.Tensor) -> torch.Tensor:
     """Double-precision sum -> float64[1] device tensor."""
     _dev(x, torch.float32, "x")
@@ -294,7 +308,8 @@ class ConvLayer:
     """Owns one mpc_conv (packed weights on the device).  Built from PyTorch-layout parameter tensors."""
 
     def __init__(self, kind: int, weight: torch.Tensor, bias: torch.Tensor, ksize: int, stride: int, act: int = 0,
-                 beta: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, in_abs: bool = False):
+                 beta: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, in_abs: bool = False,
+                 f16: bool = False):
         w = _dev(weight.detach().contiguous(), torch.float32, "weight")
         b = _dev(bias.detach().contiguous(), torch.float32, "bias")
         if kind == _lib.MPC_CONV:
@@ -310,7 +325,9 @@ class ConvLayer:
             if be.numel() != cout or tuple(ga.shape) != (cout, cout):
                 raise MpcError("GDN parameter shapes do not match cout")
         self.desc = ConvDesc(kind, cin, cout, ksize, stride, (ksize - 1) // 2,
-                             stride - 1 if kind == _lib.MPC_DECONV else 0, act, _lib.MPC_IN_ABS if in_abs else 0)
+                             stride - 1 if kind == _lib.MPC_DECONV else 0, act,
+                             (_lib.MPC_IN_ABS if in_abs else 0) | (_lib.MPC_F16 if f16 else 0))
+        self.f16 = f16
         self.device = w.device
         self.cin, self.cout, self.kind, self.stride, self.ksize = cin, cout, kind, stride, ksize
         self.small_cout = kind == _lib.MPC_DECONV and stride == 2 and cout * 4 <= 32
@@ -319,8 +336,9 @@ class ConvLayer:
         # name of the device kernel template this layer launches (matches the rocprof kernel trace)
         tiles = 1 if self.small_cout else cout // 32
         nf = tiles // (2 if tiles > 6 else 1)
-        self.kernel_name = "conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false",
-                                                               2 if self.small_cout else (1 if gdn else 0))
+        epi = 2 if self.small_cout else (1 if gdn else 0)
+        self.kernel_name = ("conv_igemm_f16_kernel<%d, %d>" % (nf, epi)) if f16 else \
+            ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
         ctx = context_for(w.device)
         h = c_void_p()
         ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
@@ -334,9 +352,11 @@ class ConvLayer:
 
     def __call__(self, x: torch.Tensor, nchw_out: bool = False, clamp01: bool = False, round_out: bool = False,
                  keep_unrounded: bool = True):
-        """x: NHWC [B,H,W,cin (3 channels padded to 4)].  Returns NHWC (or NCHW) output; with round_out
-        returns (unrounded | None, rounded)."""
-        _dev(x, torch.float32, "x")
+        """x: NHWC [B,H,W,cin (3 channels padded to 4)], fp32 (fp16 for an f16 layer).  Returns NHWC (or NCHW)
+        output of the same type (the small-cout RGB layer always returns fp32 NCHW); with round_out returns
+        (unrounded | None, rounded)."""
+        adt = torch.float16 if self.f16 else torch.float32
+        _dev(x, adt, "x")
         B, H, W, C = x.shape
         if C != (4 if self.cin <= 4 else self.cin):
             raise MpcError(f"input has {C} channels, layer expects {self.cin}")
@@ -345,7 +365,8 @@ class ConvLayer:
         shape = (B, self.cout, Ho, Wo) if nchw_out else (B, Ho, Wo, self.cout)
         flags = (_lib.MPC_OUT_NCHW if nchw_out else 0) | (_lib.MPC_OUT_CLAMP01 if clamp01 else 0) | \
                 (_lib.MPC_OUT_ROUND if round_out else 0)
-        out = torch.empty(shape, dtype=torch.float32, device=x.device) if (keep_unrounded or not round_out) else None
+        odt = torch.float32 if self.small_cout else adt
+        out = torch.empty(shape, dtype=odt, device=x.device) if (keep_unrounded or not round_out) else None
         outr = torch.empty(shape, dtype=torch.float32, device=x.device) if round_out else None
         with _timed(self.kernel_name, flops=self.flops(B, H, W)):
             context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))

@@ -13,9 +13,10 @@ class Testolina_Synthesis_net(_FusedNet):
     """Four extra 5x5 stride-1 conv + ReLU layers at latent resolution, then the usual four deconvs with IGDN
     (testolina_compressor.py:18-100).  deconv1 therefore takes N, not M, channels."""
 
-    def __init__(self, out_channel_N=192, out_channel_M=320, out_channel_fin=3, **kwargs):
+    def __init__(self, out_channel_N=192, out_channel_M=320, out_channel_fin=3, precision="fp16", **kwargs):
         super().__init__()
         N, M = out_channel_N, out_channel_M
+        self.precision = precision if (N % 64 == 0 and M % 64 == 0 and N <= 192) else "fp32"
         self.igdn1, self.igdn2, self.igdn3 = GDN(N, inverse=True), GDN(N, inverse=True), GDN(N, inverse=True)
         self.relu = nn.ReLU()
         self.convred1 = _xavier(nn.Conv2d(M, N, 5, stride=1, padding=2), math.sqrt(2 * (M + N) / (M + M)))
@@ -36,8 +37,9 @@ class Testolina_Synthesis_net(_FusedNet):
                 (D, self.deconv3, 2, G, self.igdn3, False), (D, self.deconv4, 2, _lib.MPC_ACT_NONE, None, False)]
 
     def forward_nhwc(self, y):
+        from . import ops
         ls = self.layers()
-        t = y
+        t = ops.f32_to_f16(y) if self.precision == "fp16" else y
         for layer in ls[:-1]:
             t = layer(t)
         return ls[-1](t, nchw_out=True)
@@ -63,5 +65,6 @@ class TestolinaManyPriors_ImageCompressor(manynets_compressor.Balle2017ManyPrior
     """Manypriors model with the extended decoder (testolina_compressor.py:137-185)."""
 
     def __init__(self, out_channel_N=192, out_channel_M=320, **kwargs):
+        sp = kwargs.get("synthesis_precision", "fp16")
         super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, **kwargs)
-        self.Decoder = Testolina_Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.Decoder = Testolina_Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M, precision=sp)

@@ -143,6 +143,9 @@ enum {
     MPC_ACT_EXP = 4   /* SynthesisTFCodeExp_prior_net, Balle2018PT_compressor.py:248-251 */
 };
 enum {
+    MPC_F16 = 16,          /* layer flag: fp16 operands / fp32 accumulate; activations in and out are fp16 NHWC
+                              (the small-cout RGB layer still writes fp32 NCHW).  For transforms whose output
+                              tolerance allows it (g_s: x_hat within 1e-2); g_a must stay fp32. */
     MPC_IN_ABS = 1,        /* take |x| of the input (Analysis_prior_net.forward, :123-124) */
     MPC_OUT_ROUND = 2,     /* also emit rint(out) (torch.round, manynets_compressor.py:533) */
     MPC_OUT_CLAMP01 = 4,   /* clamp(0,1) (manynets_compressor.py:537) */
@@ -157,7 +160,7 @@ typedef struct {
     int32_t pad;      /* (ksize-1)/2 */
     int32_t out_pad;  /* stride-1 for MPC_DECONV, else 0 */
     int32_t act;      /* MPC_ACT_* applied to (conv + bias) */
-    int32_t flags;    /* MPC_IN_ABS */
+    int32_t flags;    /* MPC_IN_ABS | MPC_F16 */
 } mpc_conv_desc;
 
 /* Builds one layer from PyTorch-layout device tensors: weight [cout,cin,k,k] (MPC_CONV) or
@@ -174,8 +177,12 @@ int mpc_conv_out_hw(const mpc_conv *conv, int H, int W, int *Ho, int *Wo);
 /* in: NHWC [B,H,W,cin_stride] with cin_stride = cin rounded up to a multiple of 4 (only cin = 3 is
  * padded).  out: NHWC [B,Ho,Wo,cout] (or NCHW with MPC_OUT_NCHW).  With MPC_OUT_ROUND, `out` (may be
  * NULL) receives the unrounded values and `out_round` the rounded ones. */
-int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const float *in, int B, int H, int W,
-                     int flags, float *out, float *out_round);
+int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W,
+                     int flags, void *out, float *out_round);
+/* fp32 <-> fp16 conversion of n contiguous elements (saturating to +-65504), for the boundaries of an
+ * MPC_F16 layer stack. */
+int mpc_f32_to_f16(mpc_ctx *ctx, const float *in, int64_t n, void *out_f16);
+int mpc_f16_to_f32(mpc_ctx *ctx, const void *in_f16, int64_t n, float *out);
 
 /* ---- hyperprior likelihood (abstract_model.py:226-234) -------------------------------------- */
 /* bits[i] = clamp(-ln(F(y+.5) - F(y-.5) + 1e-10)/ln 2, 0, 50) with F = Laplace(0, clamp(sigma,1e-10,1e10));

@@ -153,3 +153,34 @@ def test_layer_create_rejects_unsupported_shapes(dev, ops):
         ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2)
     with pytest.raises(_lib.MpcError):
         ops.ConvLayer(_lib.MPC_CONV, torch.zeros(192, 192, 5, 5), torch.zeros(192), 5, 2)     # CPU tensors
+
+
+@pytest.mark.parametrize("cin,act", [(256, "igdn"), (192, "igdn"), (192, "relu_conv"), (192, "rgb")])
+def test_fp16_layers_against_fp32_reference(dev, ops, cin, act):
+    """fp16-operand layers of the synthesis transform: relative error of a single layer ~1e-3."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(cin + len(act))
+    x = torch.randn(2, cin, 9, 12, generator=g)
+    xh = nhwc(x).to(dev).half()
+    if act == "igdn":
+        w, b = _w(g, cin, 192, 5, 5), _w(g, 192)
+        beta = 1.0 + torch.rand(192, generator=g)
+        gamma = 0.3 * torch.rand(192, 192, generator=g) * (torch.arange(192).view(-1, 1) / 192.0 + 0.1)
+        want = O.gdn(F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1), beta, gamma, inverse=True)
+        layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_IGDN, beta.to(dev), gamma.to(dev), f16=True)
+        got = layer(xh).float().cpu().permute(0, 3, 1, 2)
+    elif act == "relu_conv":
+        w, b = _w(g, 192, cin, 5, 5), _w(g, 192)
+        want = F.relu(F.conv2d(x, w, b, stride=1, padding=2))
+        layer = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 1, _lib.MPC_ACT_RELU, f16=True)
+        got = layer(xh).float().cpu().permute(0, 3, 1, 2)
+    else:
+        w, b = _w(g, cin, 3, 5, 5, scale=0.02), _w(g, 3, scale=0.5)
+        want = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+        layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, f16=True)
+        got = layer(xh).cpu()
+        assert got.dtype == torch.float32
+    assert got.shape == want.shape
+    err = rel_err(got, want)
+    print(f"fp16 layer {act} cin={cin}: rel err {err:.2e}")
+    assert err < 4e-3

@@ -25,9 +25,34 @@ def model(dev):
     import compression_amd as ca
     from compression_amd import manynets_compressor
     manynets_compressor.TRY_PNG_SIDESTRING = False      # the golden capture had no PNG writer (pypng absent)
-    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K)
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K, synthesis_precision="fp32")
     m.load_state_dict(synth.manypriors_state_dict(234, N, M, K, spread=True))
     return m.eval()
+
+
+@pytest.fixture(scope="module")
+def model_fp16(dev):
+    """Default configuration: g_s on fp16-operand MFMA (x_hat tolerance 1e-2), everything else identical."""
+    import compression_amd as ca
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K)
+    assert m.Decoder.precision == "fp16"
+    m.load_state_dict(synth.manypriors_state_dict(234, N, M, K, spread=True))
+    return m.eval()
+
+
+@pytest.mark.parametrize("tag,x", [("a", synth.rand_image(1, 1, 64, 96)), ("b", synth.smooth_image(2, 2, 128, 128))])
+def test_fp16_synthesis_within_tolerance(model_fp16, dev, golden, tag, x):
+    """North-star tolerance for x_hat: 1e-2 max-abs in [0,1].  Symbols / bpp are untouched by the g_s precision."""
+    g = golden("forward_std")
+    out = model_fp16(x.to(dev))
+    err = (out["reconstructed_image"].cpu() - torch.from_numpy(g[f"{tag}_xhat"])).abs().max().item()
+    rec = model_fp16.Decoder(torch.round(torch.from_numpy(g[f"{tag}_y"])).to(dev)).cpu()
+    err_raw = (rec - torch.from_numpy(g[f"{tag}_recon"])).abs().max().item()
+    print(f"[{tag}] fp16 g_s: clamped x_hat max-abs error {err:.2e}, unclamped {err_raw:.2e} "
+          f"(range {float(g[f'{tag}_recon'].min()):.1f}..{float(g[f'{tag}_recon'].max()):.1f})")
+    assert err < 1e-2
+    assert float(out["bpp_feature"]) == pytest.approx(float(g[f"{tag}_bpp_feature"]), rel=2e-5)
+    assert float(out["visual_loss"]) == pytest.approx(float(g[f"{tag}_visual_loss"]), rel=2e-2)
 
 
 def symbol_report(y_ref, sym_got, min_feat=-127):
@@ -173,13 +198,17 @@ def test_testolina_and_dc_models(dev, golden):
     from compression_amd import manynets_compressor
     manynets_compressor.TRY_PNG_SIDESTRING = False
     g = golden("forward_testolina")
-    m = ca.init_model("TestolinaManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K)
-    m.load_state_dict(synth.manypriors_state_dict(235, N, M, K, spread=True, testolina=True))
-    m.eval()
-    x = synth.smooth_image(3, 1, 64, 64).to(dev)
-    out = m(x)
-    assert (out["reconstructed_image"].cpu() - torch.from_numpy(g["xhat"])).abs().max().item() < 1e-4
-    assert float(out["bpp_feature"]) == pytest.approx(float(g["bpp_feature"]), rel=2e-5)
+    for prec, tol in (("fp32", 1e-4), ("fp16", 1e-2)):
+        m = ca.init_model("TestolinaManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K,
+                          synthesis_precision=prec)
+        m.load_state_dict(synth.manypriors_state_dict(235, N, M, K, spread=True, testolina=True))
+        m.eval()
+        x = synth.smooth_image(3, 1, 64, 64).to(dev)
+        out = m(x)
+        err = (out["reconstructed_image"].cpu() - torch.from_numpy(g["xhat"])).abs().max().item()
+        print(f"testolina {prec}: x_hat error {err:.2e}")
+        assert err < tol
+        assert float(out["bpp_feature"]) == pytest.approx(float(g["bpp_feature"]), rel=2e-5)
     dc = ca.init_model("ManyPriors", dev, std_suffix="DC", out_channel_N=N, out_channel_M=M, num_distributions=K)
     dc.load_state_dict(synth.manypriors_state_dict(234, N, M, K, spread=True))
     dc.eval()
@@ -191,7 +220,7 @@ def test_testolina_and_dc_models(dev, golden):
 def test_hyperprior_forward(dev, golden):
     import compression_amd as ca
     g = golden("forward_hyperprior")
-    m = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M)
+    m = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M, synthesis_precision="fp32")
     m.load_state_dict(synth.hyperprior_state_dict(236, N, M))
     m.eval()
     x = synth.smooth_image(4, 1, 128, 192).to(dev)
