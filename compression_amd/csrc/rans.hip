@@ -77,13 +77,34 @@ __global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const ui
     uint32_t pos = g.cap_words;
     uint32_t x = RANS_L;
     const uint32_t *p = params + gid;
-    for (uint32_t r = n; r-- > 0;) {
-        uint32_t sf = p[(int64_t)r * G];
+    auto step = [&](uint32_t sf) {
         uint32_t start = sf & 0xffffu, freq = sf >> 16;
-        if (x >= (freq << 16) && freq < 0x10000u) { buf[--pos] = (uint16_t)(x & 0xffffu); x >>= 16; }
+        if (x >= (freq << 16)) { buf[--pos] = (uint16_t)(x & 0xffffu); x >>= 16; }
         uint32_t q = x / freq;
         x = (q << 16) + (x - q * freq) + start;
+    };
+    // symbols are consumed backwards; the (start,freq) words of the next 8 are loaded while the current 8
+    // are coded (the addresses do not depend on the coder state)
+    constexpr int U = 8;
+    uint32_t r = n;
+    uint32_t cur[U], nxt[U];
+    if (r >= U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = p[(int64_t)(r - 1 - u) * G];
+        while (r >= 2 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = p[(int64_t)(r - U - 1 - u) * G];
+#pragma unroll
+            for (int u = 0; u < U; ++u) step(cur[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+            r -= U;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) step(cur[u]);
+        r -= U;
     }
+    while (r-- > 0) step(p[(int64_t)r * G]);
     buf[--pos] = (uint16_t)(x >> 16);
     buf[--pos] = (uint16_t)(x & 0xffffu);
     lens[gid] = g.cap_words - pos;
@@ -263,6 +284,144 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
     if (err && t == 0) atomicMin(&status[img], err);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast decoder for 256-symbol rows (L = 257, the standard table): the row of every symbol is staged
+// global -> registers -> LDS two symbols ahead of its use, and the symbol is found with a two-level
+// search in LDS (16 segment heads, then the 16 entries of the segment), one 16-lane ballot per level.
+// Per symbol the coder state waits on two LDS round trips instead of global-memory round trips.
+// ---------------------------------------------------------------------------------------------
+constexpr int RING = 4;                    // LDS row slots per group (rows i .. i+1 are live, 4 for slack)
+
+struct RowRegs {
+    uint4 a, b;                            // 16 u16 entries: 16t .. 16t+15 of the row
+};
+
+__device__ __forceinline__ RowRegs load_row(const uint16_t *row, int t) {
+    Row16 r = *(const Row16 *)(row + 16 * t);
+    return __builtin_bit_cast(RowRegs, r);
+}
+
+__global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, const uint16_t *__restrict__ table,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const uint8_t *__restrict__ in, size_t in_stride,
+                                                                  const uint64_t *__restrict__ nbytes,
+                                                                  int16_t *__restrict__ sym_out,
+                                                                  int32_t *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint16_t rows_sh[GROUPS_PER_BLOCK][RING][256];
+    __shared__ uint16_t heads_sh[GROUPS_PER_BLOCK][RING][16];
+    const int t = threadIdx.x & (GROUP - 1);
+    const int gi = threadIdx.x / GROUP;                    // group within the block
+    const int gshift = (threadIdx.x & 63) & ~(GROUP - 1);  // bit offset of this group in a wave ballot
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + gi;
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    if (gid >= G) return;
+    const int img = (int)(gid / g.n_streams);
+    const uint32_t stream = (uint32_t)(gid % g.n_streams);
+    const uint8_t *src = in + (size_t)img * in_stride;
+    const uint64_t nb = nbytes[img];
+    const uint32_t hdr = 16 + 2 * (uint32_t)g.n_streams;
+    int err = 0;
+    if (nb < hdr) err = -20;
+    uint32_t my_len = 0, off = hdr;
+    if (!err) {
+        const uint32_t *h4 = (const uint32_t *)src;
+        if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
+    }
+    if (!err) {
+        const uint16_t *lens = (const uint16_t *)(src + 16);
+        uint32_t acc = 0;
+        for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
+        off += 2 * group_sum(acc);
+        my_len = lens[stream];
+        if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
+    }
+    if (err) {
+        if (t == 0) atomicMin(&status[img], err);
+        return;
+    }
+    const uint16_t *words = (const uint16_t *)(src + off);
+    const uint16_t *wend = words + my_len;
+    uint32_t x = (uint32_t)words[0] | ((uint32_t)words[1] << 16);
+    const uint16_t *wp = words + 2;
+    uint32_t wnext = (wp < wend) ? *wp : 0;
+
+    uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
+    uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
+    const int32_t *img_idx = idx + (int64_t)img * g.n_loc;
+    int16_t *dst = sym_out + (int64_t)img * g.n_symbols;
+    const uint32_t M = (uint32_t)g.M;
+    const int64_t prior_stride = (int64_t)g.M * g.L;
+
+    // Row address of symbol i (clamped to the stream so that prefetches past the end stay in bounds).
+    auto row_of = [&](uint32_t i) -> const uint16_t * {
+        uint32_t ii = i < e ? i : e - 1;
+        int k = img_idx[ii / M];
+        k = (k < 0 || k >= g.K) ? 0 : k;
+        return table + (int64_t)k * prior_stride + (int64_t)(ii % M) * g.L;
+    };
+    auto stage = [&](int slot, const RowRegs &r) {
+        uint4 *d = (uint4 *)&rows_sh[gi][slot][16 * t];
+        d[0] = r.a;
+        d[1] = r.b;
+        heads_sh[gi][slot][t] = (uint16_t)(r.a.x & 0xffffu);
+    };
+    // decode one symbol from LDS slot `slot`; returns false on a corrupt stream
+    auto decode_one = [&](uint32_t i, int slot) -> bool {
+        const uint32_t xslot = x & 0xffffu;
+        uint32_t head = heads_sh[gi][slot][t];
+        unsigned long long m1 = __ballot(head <= xslot);
+        uint32_t seg_cnt = __popc((uint32_t)(m1 >> gshift) & 0xffffu);
+        if (seg_cnt == 0) { err = -24; return false; }
+        uint32_t seg = seg_cnt - 1;
+        uint32_t ent = rows_sh[gi][slot][16 * seg + t];
+        unsigned long long m2 = __ballot(ent <= xslot);
+        uint32_t s = 16 * seg + __popc((uint32_t)(m2 >> gshift) & 0xffffu) - 1;
+        uint32_t start = rows_sh[gi][slot][s];
+        uint32_t end = (s == 255u) ? 0x10000u : (uint32_t)rows_sh[gi][slot][(s + 1) & 255];
+        x = (end - start) * (x >> 16) + xslot - start;
+        if (x < RANS_L) {
+            if (wp >= wend) { err = -25; return false; }
+            x = (x << 16) | wnext;
+            ++wp;
+            wnext = (wp < wend) ? *wp : 0;
+        }
+        if (t == 0) dst[i] = (int16_t)s;
+        return true;
+    };
+
+    if (b < e) {
+        // validate the prior indices of this stream once (row_of clamps, this reports)
+        for (uint32_t l = b / M + t; l < (e + M - 1) / M; l += GROUP) {
+            int k = img_idx[l];
+            if (k < 0 || k >= g.K) err = -23;
+        }
+        if (__ballot(err != 0) >> gshift & 0xffffu) err = -23;
+    }
+    if (!err && b < e) {
+        RowRegs ra = load_row(row_of(b), t);
+        RowRegs rb = load_row(row_of(b + 1), t);
+        stage(0, ra);
+        ra = load_row(row_of(b + 2), t);
+        uint32_t i = b;
+        // invariant at the top: LDS slot (i-b)&3 holds row i; rb holds row i+1; ra holds row i+2
+        while (i < e) {
+            int s0 = (int)((i - b) & (RING - 1));
+            stage((s0 + 1) & (RING - 1), rb);
+            rb = load_row(row_of(i + 3), t);
+            if (!decode_one(i, s0)) break;
+            ++i;
+            if (i >= e) break;
+            int s1 = (int)((i - b) & (RING - 1));
+            stage((s1 + 1) & (RING - 1), ra);
+            ra = load_row(row_of(i + 3), t);
+            if (!decode_one(i, s1)) break;
+            ++i;
+        }
+    }
+    if (!err && (x != RANS_L || wp != wend)) err = -26;
+    if (err && t == 0) atomicMin(&status[img], err);
+}
+
 int check_geometry(mpc_ctx *ctx, Geometry &g, int K, int M, int L, int n_images, int64_t n_loc, int n_streams,
                    int locs_per_stream) {
     MPC_REQUIRE(ctx, K > 0 && M > 0 && L > 1 && n_images > 0 && n_loc > 0 && n_streams > 0 && locs_per_stream > 0,
@@ -351,8 +510,12 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     MPC_REQUIRE(ctx, ((uintptr_t)in % 4) == 0 && in_stride % 4 == 0, "rans_decode: in must be 4-byte aligned with a stride multiple of 4");
     int64_t G = (int64_t)n_images * n_streams;
     MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * n_images, ctx->stream));
-    decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
-        g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+    if (L == 257)
+        decode_streams_lds_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
+            g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+    else
+        decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
+            g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
     MPC_CHECK_LAUNCH(ctx, "rans decode_streams");
     return MPC_OK;
 }

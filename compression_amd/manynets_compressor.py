@@ -174,7 +174,7 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         st_cpu, nb = status.cpu(), nbytes.cpu().tolist()
         if int(st_cpu.min()) < 0:
             raise _lib.MpcError(f"rANS encoder reported {st_cpu.tolist()} (symbol outside the table or zero frequency)")
-        host = out.cpu().numpy()
+        host = out[:, :max(nb)].cpu().numpy()          # only the used part of the worst-case-sized buffer
         return [host[i, :nb[i]].tobytes() for i in range(n_images)], (n_streams, lps)
 
     def encode_batch(self, input_image, entropy_coding=True):
