@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--data", default="rand", choices=["rand", "smooth"])
+    ap.add_argument("--analysis-precision", default="f16x3", choices=["fp32", "f16x3"],
+                    help="g_a arithmetic: exact f32 MFMA, or split-precision fp16 MFMA (fp32-grade, same symbols)")
+    ap.add_argument("--synthesis-precision", default="fp16", choices=["fp32", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=48)
     return ap.parse_args()
@@ -88,7 +91,8 @@ def main():
     from compression_amd import ops
     from tests import synth
 
-    model = ca.init_model("ManyPriors", dev, out_channel_N=192, out_channel_M=256, num_distributions=64)
+    model = ca.init_model("ManyPriors", dev, out_channel_N=192, out_channel_M=256, num_distributions=64,
+                          analysis_precision=args.analysis_precision, synthesis_precision=args.synthesis_precision)
     model.load_state_dict(synth.manypriors_state_dict(234))
     model.eval()
     gen = synth.rand_image if args.data == "rand" else synth.smooth_image

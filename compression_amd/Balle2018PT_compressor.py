@@ -37,10 +37,12 @@ class _FusedNet(nn.Module):
         if getattr(self, "_fused_fp", None) != fp:
             built = []
             for kind, conv, stride, act, gdn, in_abs in self._spec():
+                small_cin = (conv.weight.shape[1] if kind == _lib.MPC_CONV else conv.weight.shape[0]) <= 4
                 built.append(ops.ConvLayer(kind, conv.weight.data, conv.bias.data, conv.kernel_size[0], stride, act,
                                            None if gdn is None else gdn.beta.data,
                                            None if gdn is None else gdn.gamma.data, in_abs,
-                                           f16=self.precision == "fp16"))
+                                           f16=self.precision == "fp16",
+                                           x3=self.precision == "f16x3" and not small_cin))
             object.__setattr__(self, "_fused", built)
             object.__setattr__(self, "_fused_fp", fp)
         return self._fused
@@ -58,10 +60,14 @@ def _check_activation(name):
 class Analysis_net(_FusedNet):
     """g_a: 4 x conv 5x5 s2, GDN after the first three (Balle2018PT_compressor.py:58-102)."""
 
-    def __init__(self, out_channel_N=192, out_channel_M=320, activation_function="GDN"):
+    def __init__(self, out_channel_N=192, out_channel_M=320, activation_function="GDN", precision="fp32"):
+        """precision "fp32": exact f32 MFMA; "f16x3": conv2-4 on split-precision fp16 MFMA (fp32-grade results,
+        activations carried as fp16 hi/lo pairs scaled by 2^8 -- needs GDN outputs bounded by 255, which
+        1/sqrt(min gamma_ii) guarantees for every sane model; checked when the layers are built)."""
         super().__init__()
         _check_activation(activation_function)
         N, M = out_channel_N, out_channel_M
+        self.precision = precision
         self.gdn1, self.gdn2, self.gdn3 = GDN(N), GDN(N), GDN(N)
         self.conv1 = _xavier(nn.Conv2d(3, N, 5, stride=2, padding=2), math.sqrt(2 * (3 + N) / 6))
         self.conv2 = _xavier(nn.Conv2d(N, N, 5, stride=2, padding=2), math.sqrt(2))
@@ -76,8 +82,23 @@ class Analysis_net(_FusedNet):
     def forward_nhwc(self, x4, round_out=False, keep_unrounded=True):
         """x4: NHWC image padded to 4 channels -> latent NHWC (or (y | None, round(y)))."""
         l1, l2, l3, l4 = self.layers()
-        t = l3(l2(l1(x4)))
+        if self.precision == "f16x3":
+            self._check_split_range()
+            t = l3(l2(l1(x4, out_split=True), out_split=True), out_split=True)
+        else:
+            t = l3(l2(l1(x4)))
         return l4(t, round_out=round_out, keep_unrounded=keep_unrounded)
+
+    def _check_split_range(self):
+        """|GDN output_i| <= 1/sqrt(gamma_eff_ii); the split format holds |v| < 255.9."""
+        fp = self._fused_fp
+        if getattr(self, "_split_checked", None) == fp:
+            return
+        for gdn in (self.gdn1, self.gdn2, self.gdn3):
+            g = torch.diagonal(gdn.gamma.data).float().clamp_min(2.0 ** -18) ** 2 - 2.0 ** -36
+            if float(g.min()) <= 1.6e-5:
+                raise _lib.MpcError("precision='f16x3' needs GDN gamma_ii > 1.6e-5 (activation bound 255); use 'fp32'")
+        object.__setattr__(self, "_split_checked", fp)
 
     def forward(self, x):
         return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous(), 4)))

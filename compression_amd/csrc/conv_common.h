@@ -11,6 +11,9 @@ constexpr int PIX_PER_BLOCK = 32 * WAVES;
 
 enum { EPI_PLAIN = 0, EPI_GDN = 1, EPI_STACKED = 2 };
 
+// Power-of-two scale of activations stored in the split-fp16 ("S16") format.
+constexpr float X3_ACT_SCALE = 256.0f;
+
 struct Phase {
     int ntaps;            // real taps of this phase
     int nchunks;          // K chunks (taps*cin/32, or ceil(taps/8) for the 4-channel input path)
@@ -37,7 +40,8 @@ struct Params {
     int cout;             // real output channels (all groups)
     int64_t w_group;      // float stride between the packed weights of consecutive cout groups
     int act;              // MPC_ACT_*
-    int flags;            // MPC_IN_ABS | MPC_OUT_CLAMP01 | MPC_OUT_NCHW
+    int flags;            // MPC_IN_ABS | MPC_OUT_CLAMP01 | MPC_OUT_NCHW | MPC_OUT_SPLIT
+    float x3_unscale;     // f16x3 path: 1 / (weight scale * activation scale)
     Phase ph[MAX_PHASES];
 };
 
@@ -49,7 +53,8 @@ struct mpc_conv {
     int nf;               // accumulator tiles per wave
     int groups;           // cout groups (grid.z)
     int64_t w_group;      // packed elements per group
-    bool cin4, stacked, f16;
+    bool cin4, stacked, f16, x3;
+    float w_scale = 1.0f;  // f16x3: power-of-two weight scale
     int nphase;
     int sy, sx, my, mx;
     Phase ph[MAX_PHASES];
@@ -61,3 +66,5 @@ struct mpc_conv {
 
 // f16 path (conv_igemm_f16.hip)
 int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
+// split-fp16 path (conv_igemm_x3.hip)
+int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);

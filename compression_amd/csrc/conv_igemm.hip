@@ -221,7 +221,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
                         float y = yv[4 * g + t];
                         o[t] = inverse ? y * n : y / n;
                     }
-                    *(float4 *)(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (p.flags & MPC_OUT_SPLIT) {
+                        // split-fp16 ("S16") output for a following f16x3 layer: [pixel][C/8][hi x8 | lo x8]
+                        _Float16 *blk = (_Float16 *)p.out + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT + (c0 & ~7)) * 2;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
+                            _Float16 hh = (_Float16)sv;
+                            blk[(c0 & 7) + t] = hh;
+                            blk[8 + (c0 & 7) + t] = (_Float16)(sv - (float)hh);
+                        }
+                    } else {
+                        *(float4 *)(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
         }
@@ -344,6 +356,48 @@ __global__ void pack_gamma_f16_kernel(const float *__restrict__ gamma_eff, int c
     out[i] = (_Float16)gamma_eff[(int64_t)cp * cout + c];
 }
 
+// max |w| as the bit pattern of a non-negative float (monotone under unsigned compare)
+__global__ void absmax_kernel(const float *__restrict__ w, int64_t n, unsigned *__restrict__ out) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// f16x3 weights: chunk = 1 tap x 32 input channels, image [kstep 2][h 2][hi|lo][cout_pad][8] fp16 of w * scale
+__global__ void pack_weights_x3_kernel(const PackDesc d, const float *__restrict__ w, float scale,
+                                       _Float16 *__restrict__ out, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int group = (int)(i / d.w_group);
+    const int64_t ig = i - (int64_t)group * d.w_group;
+    int phase = 0;
+    while (phase + 1 < d.nphase && ig >= d.w_off[phase + 1]) ++phase;
+    int64_t l = ig - d.w_off[phase];
+    const int chunk_elems = d.cout_pad * 64;
+    int chunk = (int)(l / chunk_elems);
+    int r = (int)(l % chunk_elems);
+    int jj = r & 7;
+    int row = (r >> 3) % d.cout_pad;
+    int sl = (r >> 3) / d.cout_pad;       // (ks*2 + h)*2 + part
+    int part = sl & 1, hh = (sl >> 1) & 1, ks = sl >> 2;
+    int cb = d.cin / 32;
+    int tap = chunk / cb;
+    int ci = (chunk % cb) * 32 + ks * 16 + hh * 8 + jj;
+    int co = group * d.cout_pad + row;
+    float v = 0.0f;
+    if (tap < d.ntaps[phase] && ci < d.cin && co < d.cout) {
+        int2 kk = d.kidx[d.tap_off[phase] + tap];
+        int64_t src = (d.kind == MPC_CONV)
+                          ? (((int64_t)co * d.cin + ci) * d.ksize + kk.x) * d.ksize + kk.y
+                          : (((int64_t)ci * d.cout + co) * d.ksize + kk.x) * d.ksize + kk.y;
+        v = w[src] * scale;
+    }
+    _Float16 hi = (_Float16)v;
+    out[i] = part ? (_Float16)(v - (float)hi) : hi;
+}
+
 // GDN reparametrisation (src/compression/models/GDN.py:75-81): max(x, bound)^2 - pedestal
 __global__ void gdn_reparam_kernel(const float *__restrict__ x, int64_t n, float bound, float pedestal,
                                    float *__restrict__ out) {
@@ -390,6 +444,12 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     const bool cin4 = d.cin <= 4;
     const bool stacked = d.kind == MPC_DECONV && d.stride == 2 && d.cout * 4 <= 32;
     const bool f16 = (d.flags & MPC_F16) != 0;
+    const bool x3 = (d.flags & MPC_F16X3) != 0;
+    MPC_REQUIRE(ctx, !(x3 && f16), "conv_create: MPC_F16 and MPC_F16X3 are exclusive");
+    MPC_REQUIRE(ctx, !x3 || (!cin4 && !stacked && d.cin % 32 == 0 && (d.flags & MPC_IN_ABS) == 0),
+                "conv_create: the f16x3 path needs cin % 32 == 0, cout % 32 == 0 and no MPC_IN_ABS");
+    MPC_REQUIRE(ctx, !x3 || d.act == MPC_ACT_NONE || d.act == MPC_ACT_RELU || d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN,
+                "conv_create: the f16x3 path supports no activation, ReLU, GDN and IGDN");
     MPC_REQUIRE(ctx, !f16 || (!cin4 && d.cin % 64 == 0), "conv_create: the fp16 path needs cin to be a multiple of 64");
     MPC_REQUIRE(ctx, !f16 || (d.flags & MPC_IN_ABS) == 0, "conv_create: MPC_IN_ABS is not available on the fp16 path");
     MPC_REQUIRE(ctx, !f16 || d.act == MPC_ACT_NONE || d.act == MPC_ACT_RELU || d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN,
@@ -402,13 +462,13 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     const int tiles = stacked ? 1 : d.cout / 32;
     MPC_REQUIRE(ctx, tiles == 1 || tiles == 4 || tiles == 5 || tiles == 6 || tiles == 8 || tiles == 10 || tiles == 12,
                 "conv_create: cout must be 128, 160, 192, 256, 320 or 384");
-    const int groups = tiles > 6 ? 2 : 1;
+    const int groups = tiles > 6 ? 2 : 1;   // (f16x3 uses the same split: 256 -> 2 x 128)
     const int nf = tiles / groups;
     MPC_REQUIRE(ctx, !gdn || groups == 1, "conv_create: fused GDN supports cout <= 192");
     MPC_REQUIRE(ctx, !(stacked && (gdn || d.act != MPC_ACT_NONE)), "conv_create: small-cout layer supports no activation");
 
     mpc_conv *c = new mpc_conv();
-    c->desc = d; c->device = ctx->device; c->nf = nf; c->groups = groups; c->cin4 = cin4; c->stacked = stacked; c->f16 = f16;
+    c->desc = d; c->device = ctx->device; c->nf = nf; c->groups = groups; c->cin4 = cin4; c->stacked = stacked; c->f16 = f16; c->x3 = x3;
     MPC_REQUIRE(ctx, !f16 || groups == 1, "conv_create: the fp16 path supports cout <= 192");
 
     PackDesc pd;
@@ -454,7 +514,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     for (int ph = 0; ph < pd.nphase; ++ph) {
         pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
         pd.w_off[ph] = w_total;
-        w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * (f16 ? 64 : 32);
+        w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * ((f16 || x3) ? 64 : 32);
         c->ph[ph].ntaps = pd.ntaps[ph]; c->ph[ph].nchunks = pd.nchunks[ph];
         c->ph[ph].qy = pd.qy[ph]; c->ph[ph].qx = pd.qx[ph];
         c->ph[ph].w_off = pd.w_off[ph]; c->ph[ph].tap_off = pd.tap_off[ph];
@@ -470,13 +530,32 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         mpc_conv_destroy(c);
         return MPC_EHIP;
     };
-    if ((e = hipMalloc((void **)&c->wpk, (f16 ? sizeof(_Float16) : sizeof(float)) * w_total)) != hipSuccess) return fail("hipMalloc(weights)");
+    if ((e = hipMalloc((void **)&c->wpk, ((f16 || x3) ? sizeof(_Float16) : sizeof(float)) * w_total)) != hipSuccess) return fail("hipMalloc(weights)");
     if ((e = hipMalloc((void **)&c->bias, sizeof(float) * nf * groups * 32)) != hipSuccess) return fail("hipMalloc(bias)");
     if ((e = hipMalloc((void **)&c->taps, sizeof(int2) * ntap_total)) != hipSuccess) return fail("hipMalloc(taps)");
     if ((e = hipMemcpyAsync(c->taps, pd.taps, sizeof(int2) * ntap_total, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy taps");
     if ((e = hipMemsetAsync(c->bias, 0, sizeof(float) * nf * groups * 32, ctx->stream)) != hipSuccess) return fail("memset bias");
     if ((e = hipMemcpyAsync(c->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess) return fail("copy bias");
-    pack_weights_kernel<<<dim3((unsigned)mpc_cdiv(w_total, 256)), dim3(256), 0, ctx->stream>>>(pd, weight, c->wpk, w_total);
+    if (x3) {
+        // per-layer power-of-two weight scale: max |w| * scale in [2^13, 2^14)
+        unsigned *mx = nullptr, mx_h = 0;
+        const int64_t nw = (int64_t)d.cin * d.cout * d.ksize * d.ksize;
+        if ((e = hipMalloc((void **)&mx, sizeof(unsigned))) != hipSuccess) return fail("hipMalloc(absmax)");
+        (void)hipMemsetAsync(mx, 0, sizeof(unsigned), ctx->stream);
+        absmax_kernel<<<dim3(256), dim3(256), 0, ctx->stream>>>(weight, nw, mx);
+        e = hipMemcpyAsync(&mx_h, mx, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(mx);
+        if (e != hipSuccess) return fail("absmax");
+        float amax;
+        memcpy(&amax, &mx_h, sizeof(float));
+        int ex = 0;
+        if (amax > 0.0f && amax < 1e30f) (void)frexpf(amax, &ex);      // amax = m * 2^ex, m in [0.5, 1)
+        c->w_scale = ldexpf(1.0f, 14 - ex);
+        pack_weights_x3_kernel<<<dim3((unsigned)mpc_cdiv(w_total, 256)), dim3(256), 0, ctx->stream>>>(pd, weight, c->w_scale, (_Float16 *)c->wpk, w_total);
+    } else {
+        pack_weights_kernel<<<dim3((unsigned)mpc_cdiv(w_total, 256)), dim3(256), 0, ctx->stream>>>(pd, weight, c->wpk, w_total);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return fail("pack_weights launch");
     if (gdn) {
         const float pedestal = 0x1p-36f;
@@ -529,7 +608,7 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
     const bool want_round = (flags & MPC_OUT_ROUND) != 0;
     MPC_REQUIRE(ctx, want_round ? out_round != nullptr : out != nullptr, "conv_forward: output pointer is NULL");
     const bool gdn = d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN;
-    MPC_REQUIRE(ctx, !(gdn && (flags & (MPC_OUT_ROUND | MPC_OUT_NCHW | MPC_OUT_CLAMP01))), "conv_forward: GDN layers write plain NHWC only");
+    MPC_REQUIRE(ctx, !(gdn && (flags & (MPC_OUT_ROUND | MPC_OUT_NCHW | MPC_OUT_CLAMP01))), "conv_forward: GDN layers write NHWC only");
     MPC_REQUIRE(ctx, !(c->stacked && want_round), "conv_forward: rounding is not available on the small-cout layer");
     MPC_REQUIRE(ctx, !c->stacked || (flags & MPC_OUT_NCHW), "conv_forward: the small-cout layer writes NCHW only (pass MPC_OUT_NCHW)");
     Params p;
@@ -549,6 +628,14 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
 
     p.w_group = c->w_group;
     const int np = c->nphase, ng = c->groups;
+    if (c->x3) {
+        MPC_REQUIRE(ctx, !(flags & (MPC_OUT_NCHW | MPC_OUT_CLAMP01)), "conv_forward: the f16x3 path writes NHWC fp32 or the split format only");
+        MPC_REQUIRE(ctx, !((flags & MPC_OUT_SPLIT) && want_round), "conv_forward: rounding needs the fp32 output");
+        p.cin_blocks = d.cin / 32;
+        p.x3_unscale = 1.0f / (c->w_scale * X3_ACT_SCALE);
+        return mpc_conv_launch_x3(ctx, p, c);
+    }
+    MPC_REQUIRE(ctx, !(flags & MPC_OUT_SPLIT) || (gdn && !c->f16), "conv_forward: MPC_OUT_SPLIT is available on fp32 GDN layers and f16x3 layers");
     if (c->f16) {
         MPC_REQUIRE(ctx, !want_round && !(flags & MPC_OUT_NCHW && !c->stacked), "conv_forward: the fp16 path writes fp16 NHWC (fp32 NCHW on the small-cout layer) and has no rounding output");
         p.cin_blocks = d.cin / 64;

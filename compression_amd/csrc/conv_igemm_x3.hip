@@ -1,0 +1,260 @@
+// Split-precision ("f16x3") variant of the implicit-GEMM transform kernel for the analysis transform:
+// fp32-grade results on the fp16 matrix pipe.
+//
+// Every fp32 operand v (pre-scaled by a power of two so that it sits well inside fp16's range) is
+// carried as hi = fp16(v), lo = fp16(v - hi): 22 significant bits.  A product is evaluated as
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// dropping only a_lo*b_lo (2^-22 relative).  Products of fp16 values are exact in the fp32
+// accumulator, and the accumulation chain is K/16 steps long instead of K, so the result is as close
+// to the exact dot product as the f32-MFMA kernel's (whose 4800-step fma chain dominates its own
+// error).  What has to hold for the symbols: latents that differ from the reference only when they
+// sit within ~1e-6 of a rounding tie.
+//
+// Formats:
+//   activations "S16": [pixel][C/8][hi x8 | lo x8] fp16, values scaled by ACT_SCALE = 2^8
+//                      (one 32-byte read per lane per k-step brings both halves);
+//   weights: scaled by a per-layer power of two (max |w| -> [2^13, 2^14)), packed per K chunk
+//            (1 tap x 32 input channels) as [kstep 2][h 2][hi|lo][cout][8] fp16.
+// GDN stays on the exact f32 MFMA (4 % of the MACs) on the unscaled fp32 accumulators.
+// Same orientation / work decomposition / LDS weight staging as conv_igemm.hip.
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
+
+__device__ __forceinline__ void split_store4(_Float16 *blk, int off, const float (&v)[4]) {
+    // v already scaled; hi at blk[off..off+3], lo at blk[8+off..]
+    half4 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float s = fminf(fmaxf(v[t], -65504.0f), 65504.0f);
+        _Float16 hh = (_Float16)s;
+        hi[t] = hh;
+        lo[t] = (_Float16)(s - (float)hh);
+    }
+    *(half4 *)(blk + off) = hi;
+    *(half4 *)(blk + 8 + off) = lo;
+}
+
+template <int NF, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
+    constexpr int COUT = NF * 32;
+    constexpr int CHUNK_F4 = COUT * 8;                    // 16-byte slots per weight chunk (2*2*2*COUT)
+    constexpr int STAGE = CHUNK_F4 / 256;
+    extern __shared__ float4 lds[];                       // 2 x CHUNK_F4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const Phase ph = p.ph[blockIdx.y];
+    const int2 *taps = p.taps + ph.tap_off;
+    const int cg = blockIdx.z * COUT;
+
+    const int64_t pix = (int64_t)blockIdx.x * PIX_PER_BLOCK + wave * 32 + j;
+    const bool pvalid = pix < p.P;
+    int b = 0, by = 0, bx = 0;
+    if (pvalid) {
+        int64_t hw = (int64_t)p.Hb * p.Wb;
+        b = (int)(pix / hw);
+        int rem = (int)(pix - (int64_t)b * hw);
+        by = rem / p.Wb;
+        bx = rem - by * p.Wb;
+    }
+    // S16 input: 2*Cs halfs per pixel
+    const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs * 2;
+
+    auto load_b = [&](int chunk, float4 (&dst)[4]) {      // [ks][hi|lo]
+        int tap = chunk / p.cin_blocks;
+        int cb = chunk - tap * p.cin_blocks;
+        int2 d = taps[tap];
+        int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
+        bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const _Float16 *src = in_b + ((int64_t)iy * p.Wi + ix) * p.Cs * 2 + (cb * 4 + h) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), vl = vh;
+            if (ok) {
+                vh = *(const float4 *)(src + ks * 32);
+                vl = *(const float4 *)(src + ks * 32 + 8);
+            }
+            dst[2 * ks] = vh;
+            dst[2 * ks + 1] = vl;
+        }
+    };
+    const float4 *wsrc = (const float4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group + ph.w_off);
+    auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
+        const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
+#pragma unroll
+        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * 256];
+    };
+    auto store_w = [&](int buf, const float4 (&src)[STAGE]) {
+        float4 *d = lds + buf * CHUNK_F4 + tid;
+#pragma unroll
+        for (int r = 0; r < STAGE; ++r) d[r * 256] = src[r];
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    float4 bcur[4], bnext[4], wreg[STAGE];
+    load_w(0, wreg);
+    load_b(0, bcur);
+    store_w(0, wreg);
+    __syncthreads();
+
+    const int nch = ph.nchunks;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int nxt = (ch + 1 < nch) ? ch + 1 : ch;
+        load_w(nxt, wreg);
+        load_b(nxt, bnext);
+        // slot index ((ks*2 + h)*2 + part)*COUT + cout
+        const float4 *wl = lds + (ch & 1) * CHUNK_F4 + (h * 2) * COUT + j;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 bh = as_half8(bcur[2 * ks]), bl = as_half8(bcur[2 * ks + 1]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const half8 ah = as_half8(wl[(ks * 4) * COUT + f * 32]);
+                const half8 al = as_half8(wl[(ks * 4 + 1) * COUT + f * 32]);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);
+            }
+        }
+        store_w((ch + 1) & 1, wreg);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+    }
+
+    // ---- epilogue: undo the operand scales, add bias ---------------------------------------------
+    const float unscale = p.x3_unscale;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 bb = *(const float4 *)(p.bias + cg + 32 * f + 8 * g + 4 * h);
+            acc[f][4 * g + 0] = acc[f][4 * g + 0] * unscale + bb.x;
+            acc[f][4 * g + 1] = acc[f][4 * g + 1] * unscale + bb.y;
+            acc[f][4 * g + 2] = acc[f][4 * g + 2] * unscale + bb.z;
+            acc[f][4 * g + 3] = acc[f][4 * g + 3] * unscale + bb.w;
+        }
+    const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
+    const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+    const bool out_split = (p.flags & MPC_OUT_SPLIT) != 0;
+
+    if constexpr (EPI == EPI_GDN) {
+        const bool inverse = p.act == MPC_ACT_IGDN;
+#pragma unroll 1
+        for (int fo = 0; fo < NF; ++fo) {
+            f32x16 nrm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
+            const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                float4 ga[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ga[g] = *(const float4 *)(grow + 32 * f + 8 * g);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float av[4] = {ga[g].x, ga[g].y, ga[g].z, ga[g].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float y = acc[f][4 * g + t];
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], y * y, nrm, 0, 0, 0);
+                    }
+                }
+            }
+            f32x16 yv;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+                if (f == fo) yv = acc[f];
+            if (pvalid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int c0 = 32 * fo + 8 * g + 4 * h;
+                    float4 be = *(const float4 *)(p.beta + c0);
+                    const float bev[4] = {be.x, be.y, be.z, be.w};
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float n = sqrtf(nrm[4 * g + t] + bev[t]);
+                        float y = yv[4 * g + t];
+                        o[t] = inverse ? y * n : y / n;
+                    }
+                    if (out_split) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) o[t] *= X3_ACT_SCALE;
+                        split_store4((_Float16 *)p.out + (opix * COUT + (c0 & ~7)) * 2, c0 & 7, o);
+                    } else {
+                        *(float4 *)((float *)p.out + opix * COUT + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+    } else {
+        if (!pvalid) return;
+        float *out_f = (float *)p.out;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int c0 = cg + 32 * f + 8 * g + 4 * h;
+                float o[4], orr[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float v = acc[f][4 * g + t];
+                    if (p.act == MPC_ACT_RELU) v = fmaxf(v, 0.0f);
+                    o[t] = v;
+                    orr[t] = rintf(v);
+                }
+                if (out_split) {
+                    float os[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) os[t] = o[t] * X3_ACT_SCALE;
+                    split_store4((_Float16 *)p.out + (opix * p.cout + (c0 & ~7)) * 2, c0 & 7, os);
+                } else {
+                    if (out_f) *(float4 *)(out_f + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (p.out_round) *(float4 *)(p.out_round + opix * p.cout + c0) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+                }
+            }
+    }
+}
+
+template <int NF, int EPI>
+int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
+    size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
+    auto kern = conv_igemm_x3_kernel<NF, EPI>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int64_t bx = mpc_cdiv(p.P, PIX_PER_BLOCK);
+    MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
+    kern<<<dim3((unsigned)bx, (unsigned)nphase, (unsigned)groups), dim3(256), lds, ctx->stream>>>(p);
+    MPC_CHECK_LAUNCH(ctx, "conv_igemm_x3");
+    return MPC_OK;
+}
+
+}  // namespace
+
+int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
+    const int np = c->nphase, ng = c->groups;
+    if (gdn) {
+        if (c->nf == 4) return launch<4, EPI_GDN>(ctx, p, np, ng);
+        if (c->nf == 6) return launch<6, EPI_GDN>(ctx, p, np, ng);
+    } else {
+        if (c->nf == 4) return launch<4, EPI_PLAIN>(ctx, p, np, ng);
+        if (c->nf == 6) return launch<6, EPI_PLAIN>(ctx, p, np, ng);
+    }
+    MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16x3): unsupported layer shape (cout/32 = %d)", c->nf);
+}

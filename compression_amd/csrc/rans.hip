@@ -340,10 +340,13 @@ __global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, con
         return;
     }
     const uint16_t *words = (const uint16_t *)(src + off);
-    const uint16_t *wend = words + my_len;
     uint32_t x = (uint32_t)words[0] | ((uint32_t)words[1] << 16);
-    const uint16_t *wp = words + 2;
-    uint32_t wnext = (wp < wend) ? *wp : 0;
+    // Renormalisation words are kept in a 32-word register window spread over the group's 16 lanes (lane t
+    // holds words wbase+t and wbase+16+t) and read with a lane shuffle, so the coder state never waits on a
+    // global load; the window is refilled 16 words ahead of its use.
+    uint32_t wpos = 2, wbase = 2;                          // next word to consume; first word of the window
+    auto fetch = [&](uint32_t k) -> uint32_t { return k < my_len ? (uint32_t)words[k] : 0u; };
+    uint32_t win0 = fetch(wbase + t), win1 = fetch(wbase + 16 + t);
 
     uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
     uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
@@ -380,10 +383,15 @@ __global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, con
         uint32_t end = (s == 255u) ? 0x10000u : (uint32_t)rows_sh[gi][slot][(s + 1) & 255];
         x = (end - start) * (x >> 16) + xslot - start;
         if (x < RANS_L) {
-            if (wp >= wend) { err = -25; return false; }
-            x = (x << 16) | wnext;
-            ++wp;
-            wnext = (wp < wend) ? *wp : 0;
+            if (wpos >= my_len) { err = -25; return false; }
+            uint32_t w = __shfl(win0, (int)(wpos - wbase), GROUP);
+            x = (x << 16) | w;
+            ++wpos;
+            if (wpos - wbase == 16) {                       // first half consumed: slide the window
+                win0 = win1;
+                wbase += 16;
+                win1 = fetch(wbase + 16 + t);
+            }
         }
         if (t == 0) dst[i] = (int16_t)s;
         return true;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, con
             ++i;
         }
     }
-    if (!err && (x != RANS_L || wp != wend)) err = -26;
+    if (!err && (x != RANS_L || wpos != my_len)) err = -26;
     if (err && t == 0) atomicMin(&status[img], err);
 }
 

@@ -53,6 +53,10 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         sp = kwargs.pop("synthesis_precision", None)
         if sp is not None:
             self.Decoder.precision = sp
+        # "fp32" (default): g_a on the exact f32 MFMA; "f16x3": conv2-4 on split-precision fp16 MFMA
+        ap = kwargs.pop("analysis_precision", None)
+        if ap is not None:
+            self.Encoder.precision = ap
         self.num_distributions = num_distributions
         self.dist_patch_size = dist_patch_size
         self.bitEstimators = MultiHeadBitEstimator(self.nchans_per_prior, nb_head=num_distributions,

@@ -309,7 +309,7 @@ class ConvLayer:
 
     def __init__(self, kind: int, weight: torch.Tensor, bias: torch.Tensor, ksize: int, stride: int, act: int = 0,
                  beta: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, in_abs: bool = False,
-                 f16: bool = False):
+                 f16: bool = False, x3: bool = False):
         w = _dev(weight.detach().contiguous(), torch.float32, "weight")
         b = _dev(bias.detach().contiguous(), torch.float32, "bias")
         if kind == _lib.MPC_CONV:
@@ -326,8 +326,9 @@ class ConvLayer:
                 raise MpcError("GDN parameter shapes do not match cout")
         self.desc = ConvDesc(kind, cin, cout, ksize, stride, (ksize - 1) // 2,
                              stride - 1 if kind == _lib.MPC_DECONV else 0, act,
-                             (_lib.MPC_IN_ABS if in_abs else 0) | (_lib.MPC_F16 if f16 else 0))
-        self.f16 = f16
+                             (_lib.MPC_IN_ABS if in_abs else 0) | (_lib.MPC_F16 if f16 else 0) |
+                             (_lib.MPC_F16X3 if x3 else 0))
+        self.f16, self.x3 = f16, x3
         self.device = w.device
         self.cin, self.cout, self.kind, self.stride, self.ksize = cin, cout, kind, stride, ksize
         self.small_cout = kind == _lib.MPC_DECONV and stride == 2 and cout * 4 <= 32
@@ -337,7 +338,8 @@ class ConvLayer:
         tiles = 1 if self.small_cout else cout // 32
         nf = tiles // (2 if tiles > 6 else 1)
         epi = 2 if self.small_cout else (1 if gdn else 0)
-        self.kernel_name = ("conv_igemm_f16_kernel<%d, %d>" % (nf, epi)) if f16 else \
+        self.kernel_name = ("conv_igemm_x3_kernel<%d, %d>" % (nf, epi)) if x3 else \
+            ("conv_igemm_f16_kernel<%d, %d>" % (nf, epi)) if f16 else \
             ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
         ctx = context_for(w.device)
         h = c_void_p()
@@ -351,21 +353,30 @@ class ConvLayer:
         return ho.value, wo.value
 
     def __call__(self, x: torch.Tensor, nchw_out: bool = False, clamp01: bool = False, round_out: bool = False,
-                 keep_unrounded: bool = True):
-        """x: NHWC [B,H,W,cin (3 channels padded to 4)], fp32 (fp16 for an f16 layer).  Returns NHWC (or NCHW)
-        output of the same type (the small-cout RGB layer always returns fp32 NCHW); with round_out returns
-        (unrounded | None, rounded)."""
-        adt = torch.float16 if self.f16 else torch.float32
+                 keep_unrounded: bool = True, out_split: bool = False):
+        """x: NHWC [B,H,W,cin (3 channels padded to 4)] fp32; fp16 for an f16 layer; the split-fp16 "S16" tensor
+        [B,H,W,cin/8,16] fp16 for an f16x3 layer.  Returns NHWC (or NCHW) output of the layer's activation type
+        (the small-cout RGB layer always returns fp32 NCHW; out_split returns an S16 tensor [B,Ho,Wo,cout/8,16]);
+        with round_out returns (unrounded | None, rounded)."""
+        adt = torch.float16 if (self.f16 or self.x3) else torch.float32
         _dev(x, adt, "x")
-        B, H, W, C = x.shape
-        if C != (4 if self.cin <= 4 else self.cin):
-            raise MpcError(f"input has {C} channels, layer expects {self.cin}")
+        if self.x3:
+            if x.dim() != 5 or x.shape[3] * 8 != self.cin or x.shape[4] != 16:
+                raise MpcError(f"f16x3 layer expects a split tensor [B,H,W,{self.cin // 8},16], got {tuple(x.shape)}")
+            B, H, W = x.shape[:3]
+        else:
+            B, H, W, C = x.shape
+            if C != (4 if self.cin <= 4 else self.cin):
+                raise MpcError(f"input has {C} channels, layer expects {self.cin}")
         Ho, Wo = self.out_hw(H, W)
         nchw_out = nchw_out or self.small_cout
-        shape = (B, self.cout, Ho, Wo) if nchw_out else (B, Ho, Wo, self.cout)
         flags = (_lib.MPC_OUT_NCHW if nchw_out else 0) | (_lib.MPC_OUT_CLAMP01 if clamp01 else 0) | \
-                (_lib.MPC_OUT_ROUND if round_out else 0)
-        odt = torch.float32 if self.small_cout else adt
+                (_lib.MPC_OUT_ROUND if round_out else 0) | (_lib.MPC_OUT_SPLIT if out_split else 0)
+        if out_split:
+            shape, odt = (B, Ho, Wo, self.cout // 8, 16), torch.float16
+        else:
+            shape = (B, self.cout, Ho, Wo) if nchw_out else (B, Ho, Wo, self.cout)
+            odt = torch.float32 if (self.small_cout or self.x3) else adt
         out = torch.empty(shape, dtype=odt, device=x.device) if (keep_unrounded or not round_out) else None
         outr = torch.empty(shape, dtype=torch.float32, device=x.device) if round_out else None
         with _timed(self.kernel_name, flops=self.flops(B, H, W)):

@@ -146,6 +146,12 @@ enum {
     MPC_F16 = 16,          /* layer flag: fp16 operands / fp32 accumulate; activations in and out are fp16 NHWC
                               (the small-cout RGB layer still writes fp32 NCHW).  For transforms whose output
                               tolerance allows it (g_s: x_hat within 1e-2); g_a must stay fp32. */
+    MPC_F16X3 = 32,        /* layer flag: split-precision fp16 MFMA (a = hi + lo, three MFMAs per product, fp32
+                              accumulate) -- fp32-grade results on the fp16 matrix pipe, for g_a.  The INPUT
+                              is in the split format "S16": [pixel][C/8][hi x8 | lo x8] fp16, scaled by 2^8
+                              (4 bytes per element); the output is fp32 NHWC or, with MPC_OUT_SPLIT, S16. */
+    MPC_OUT_SPLIT = 128,   /* forward flag: write the output in the S16 split format (fp32 GDN layers and
+                              MPC_F16X3 layers), for a following MPC_F16X3 layer */
     MPC_IN_ABS = 1,        /* take |x| of the input (Analysis_prior_net.forward, :123-124) */
     MPC_OUT_ROUND = 2,     /* also emit rint(out) (torch.round, manynets_compressor.py:533) */
     MPC_OUT_CLAMP01 = 4,   /* clamp(0,1) (manynets_compressor.py:537) */
@@ -160,7 +166,7 @@ typedef struct {
     int32_t pad;      /* (ksize-1)/2 */
     int32_t out_pad;  /* stride-1 for MPC_DECONV, else 0 */
     int32_t act;      /* MPC_ACT_* applied to (conv + bias) */
-    int32_t flags;    /* MPC_IN_ABS | MPC_F16 */
+    int32_t flags;    /* MPC_IN_ABS | MPC_F16 | MPC_F16X3 */
 } mpc_conv_desc;
 
 /* Builds one layer from PyTorch-layout device tensors: weight [cout,cin,k,k] (MPC_CONV) or

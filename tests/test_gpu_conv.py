@@ -184,3 +184,53 @@ def test_fp16_layers_against_fp32_reference(dev, ops, cin, act):
     err = rel_err(got, want)
     print(f"fp16 layer {act} cin={cin}: rel err {err:.2e}")
     assert err < 4e-3
+
+
+def to_split(x_nhwc, scale=256.0):
+    """fp32 NHWC -> S16 split tensor [B,H,W,C/8,16] (hi x8 | lo x8), the format f16x3 layers read."""
+    v = (x_nhwc * scale).float()
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    B, H, W, C = x_nhwc.shape
+    return torch.cat([hi.view(B, H, W, C // 8, 8), lo.view(B, H, W, C // 8, 8)], dim=-1).contiguous()
+
+
+def from_split(s, scale=256.0):
+    B, H, W, nb, _ = s.shape
+    return ((s[..., :8].float() + s[..., 8:].float()) / scale).reshape(B, H, W, nb * 8)
+
+
+@pytest.mark.parametrize("cout,gdn", [(192, True), (256, False)])
+def test_split_precision_layer_is_fp32_grade(dev, ops, cout, gdn):
+    """f16x3 (hi/lo fp16, three MFMAs per product): error against an fp64 reference must be at the level of
+    the f32 kernel's, i.e. ~1e-6 relative, not fp16's 1e-3."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(2, 192, 20, 28, generator=g)
+    w, b = _w(g, cout, 192, 5, 5, scale=0.02), _w(g, cout)
+    beta, gamma = synth._gdn(g, cout) if gdn else (None, None)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+    if gdn:
+        be, ga = O.gdn_effective(beta, gamma)
+        ref = ref / torch.sqrt(F.conv2d(ref ** 2, ga.double().view(cout, cout, 1, 1), be.double()))
+    act = _lib.MPC_ACT_GDN if gdn else _lib.MPC_ACT_NONE
+    args = (beta.to(dev), gamma.to(dev)) if gdn else (None, None)
+    l32 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, act, *args)
+    lx3 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, act, *args, x3=True)
+    xs = to_split(nhwc(x)).to(dev)
+    x_rt = from_split(xs.cpu())                        # what the split format actually holds (22 bits)
+    assert (x_rt - nhwc(x)).abs().max().item() < 1e-6
+    got32 = l32(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2).double()
+    gotx3 = lx3(xs).cpu().permute(0, 3, 1, 2).double()
+    e32 = ((got32 - ref).abs().max() / ref.abs().max()).item()
+    ex3 = ((gotx3 - ref).abs().max() / ref.abs().max()).item()
+    print(f"cout={cout} gdn={gdn}: rel err vs fp64  f32-MFMA {e32:.2e}   f16x3 {ex3:.2e}")
+    assert ex3 < 5e-6 and ex3 < 2 * e32 + 1e-7
+    # split output feeds the next layer: round trip through the S16 writer
+    if gdn:
+        outs = lx3(xs, out_split=True)
+        back = from_split(outs.cpu()).permute(0, 3, 1, 2).double()
+        assert ((back - ref).abs().max() / ref.abs().max()).item() < 5e-6
+        outs32 = l32(nhwc(x).to(dev), out_split=True)
+        back32 = from_split(outs32.cpu()).permute(0, 3, 1, 2).double()
+        assert ((back32 - ref).abs().max() / ref.abs().max()).item() < 5e-6

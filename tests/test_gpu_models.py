@@ -248,3 +248,24 @@ def test_training_mode_and_cpu_are_refused(model, dev):
         model.eval()
     with pytest.raises(MpcError):
         model(synth.rand_image(1, 1, 64, 64))
+
+
+def test_split_precision_analysis_keeps_symbols(dev, golden):
+    """g_a with conv2-4 on split-precision fp16 MFMA: the symbols must still match the reference up to
+    rounding ties (<= 1e-5 of the symbols)."""
+    import compression_amd as ca
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K, analysis_precision="f16x3")
+    m.load_state_dict(synth.manypriors_state_dict(234, N, M, K, spread=True))
+    m.eval()
+    g = golden("forward_std")
+    for tag, x in (("a", synth.rand_image(1, 1, 64, 96)), ("b", synth.smooth_image(2, 2, 128, 128))):
+        sym, idx, h, w = m.encode_batch(x.to(dev), entropy_coding=False)
+        nflip, tie = symbol_report(torch.from_numpy(g[f"{tag}_y"]), sym)
+        print(f"[{tag}] f16x3 g_a: symbol flips {nflip} / {sym.numel()} (max tie distance {tie:.2e})")
+        assert nflip <= 1 and tie < 1e-4
+    gk = golden("kodak_digest")
+    x = synth.rand_image(234, 1, 512, 768).to(dev)
+    sym, indices, h, w = m.encode(x, entropy_coding=False)
+    flips = int((sym.cpu().numpy() != gk["sym"]).sum())
+    print(f"768x512 f16x3 g_a: symbol flips {flips} / {sym.numel()}")
+    assert flips <= 4
