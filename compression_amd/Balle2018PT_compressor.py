@@ -36,13 +36,18 @@ class _FusedNet(nn.Module):
         fp = self._fingerprint()
         if getattr(self, "_fused_fp", None) != fp:
             built = []
+            bound = 1.0          # |input| bound along the stack: image in [0,1], then 1/sqrt(min gamma_ii) after a GDN
             for kind, conv, stride, act, gdn, in_abs in self._spec():
-                small_cin = (conv.weight.shape[1] if kind == _lib.MPC_CONV else conv.weight.shape[0]) <= 4
                 built.append(ops.ConvLayer(kind, conv.weight.data, conv.bias.data, conv.kernel_size[0], stride, act,
                                            None if gdn is None else gdn.beta.data,
                                            None if gdn is None else gdn.gamma.data, in_abs,
-                                           f16=self.precision == "fp16",
-                                           x3=self.precision == "f16x3" and not small_cin))
+                                           f16=self.precision == "fp16", x3=self.precision == "f16x3",
+                                           in_bound=bound if self.precision == "f16x3" else 0.0))
+                if gdn is not None and not gdn.inverse:
+                    gii = torch.diagonal(gdn.gamma.data).float().clamp_min(2.0 ** -18) ** 2 - 2.0 ** -36
+                    bound = float(1.0 / torch.sqrt(gii.min().clamp_min(1e-12)))
+                else:
+                    bound = 0.0
             object.__setattr__(self, "_fused", built)
             object.__setattr__(self, "_fused_fp", fp)
         return self._fused

@@ -27,7 +27,8 @@ class MpcError(RuntimeError):
 
 
 class ConvDesc(ctypes.Structure):
-    _fields_ = [(n, c_int32) for n in ("kind", "cin", "cout", "ksize", "stride", "pad", "out_pad", "act", "flags")]
+    _fields_ = [(n, c_int32) for n in ("kind", "cin", "cout", "ksize", "stride", "pad", "out_pad", "act", "flags")] + \
+               [("in_bound", c_float)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/mpc.h

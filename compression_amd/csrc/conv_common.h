@@ -42,9 +42,49 @@ struct Params {
     int act;              // MPC_ACT_*
     int flags;            // MPC_IN_ABS | MPC_OUT_CLAMP01 | MPC_OUT_NCHW | MPC_OUT_SPLIT
     float x3_unscale;     // f16x3 path: 1 / (weight scale * activation scale)
+    const void *gamma_x3; // f16x3 GDN: fp16 hi/lo gamma in MFMA operand order (null -> exact f32 GDN)
+    float y2_scale;       // f16x3 GDN: power-of-two scale of y^2 (0 -> exact f32 GDN)
+    float gdn_unscale;    // 1 / (gamma scale * y2_scale)
     Phase ph[MAX_PHASES];
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-private transposing store for the GDN epilogues.  In the accumulator layout a lane owns ONE
+// pixel and a few channels, so a direct store writes 8-16 bytes per lane at a whole-pixel stride:
+// partial cache lines, the slowest way to write HBM.  Instead each wave collects up to ROW_BYTES
+// contiguous output bytes of each of its 32 pixels in LDS (the weight buffers are free once the K loop
+// has ended) and flushes them with 16-byte stores in which consecutive lanes cover consecutive bytes
+// of a pixel's row: full 128-byte lines.
+// ---------------------------------------------------------------------------------------------
+constexpr int TS_ROW_BYTES = 384;                 // bytes of one pixel collected per round
+constexpr int TS_ROW_PAD = 400;                   // LDS row pitch (odd multiple of 16 B: conflict-free b128)
+constexpr int TS_WAVE_BYTES = 32 * TS_ROW_PAD + 32 * 8;   // rows + the 32 output-pixel indices
+constexpr int TS_BLOCK_BYTES = WAVES * TS_WAVE_BYTES;
+
+struct TransStore {
+    char *rows;          // this wave's [32][TS_ROW_PAD]
+    long long *opix;     // this wave's [32] output pixel index (-1 = not stored)
+    int lane;
+
+    __device__ __forceinline__ void init(char *lds_base, int wave, int lane_, int j, int h, long long my_opix) {
+        rows = lds_base + wave * TS_WAVE_BYTES;
+        opix = (long long *)(rows + 32 * TS_ROW_PAD);
+        lane = lane_;
+        if (h == 0) opix[j] = my_opix;
+    }
+    // pointer to byte `off` of pixel j's row of the current round
+    __device__ __forceinline__ char *at(int j, int off) const { return rows + j * TS_ROW_PAD + off; }
+    // write `nbytes` (multiple of 16) per pixel to out + opix*pixel_bytes + col_off
+    __device__ __forceinline__ void flush(char *out, long long pixel_bytes, int col_off, int nbytes) const {
+        const int pieces = nbytes >> 4, total = 32 * pieces;
+        for (int i = lane; i < total; i += 64) {
+            int px = i / pieces, pc = i - px * pieces;
+            long long o = opix[px];
+            if (o >= 0) *(float4 *)(out + o * pixel_bytes + col_off + pc * 16) = *(const float4 *)(rows + px * TS_ROW_PAD + pc * 16);
+        }
+    }
+};
 
 // Layer object behind the opaque mpc_conv handle.
 struct mpc_conv {
@@ -55,6 +95,8 @@ struct mpc_conv {
     int64_t w_group;      // packed elements per group
     bool cin4, stacked, f16, x3;
     float w_scale = 1.0f;  // f16x3: power-of-two weight scale
+    void *gamma_x3 = nullptr;
+    float gamma_scale = 0.0f, y2_scale = 0.0f;
     int nphase;
     int sy, sx, my, mx;
     Phase ph[MAX_PHASES];

@@ -224,13 +224,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
                     if (p.flags & MPC_OUT_SPLIT) {
                         // split-fp16 ("S16") output for a following f16x3 layer: [pixel][C/8][hi x8 | lo x8]
                         _Float16 *blk = (_Float16 *)p.out + ((((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT + (c0 & ~7)) * 2;
+                        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                        half4_t hi4, lo4;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
                             _Float16 hh = (_Float16)sv;
-                            blk[(c0 & 7) + t] = hh;
-                            blk[8 + (c0 & 7) + t] = (_Float16)(sv - (float)hh);
+                            hi4[t] = hh;
+                            lo4[t] = (_Float16)(sv - (float)hh);
                         }
+                        *(half4_t *)(blk + (c0 & 7)) = hi4;
+                        *(half4_t *)(blk + 8 + (c0 & 7)) = lo4;
                     } else {
                         *(float4 *)(orow + c0) = make_float4(o[0], o[1], o[2], o[3]);
                     }
@@ -365,6 +369,35 @@ __global__ void absmax_kernel(const float *__restrict__ w, int64_t n, unsigned *
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
+// max over output channels of sum |w[co, :, :, :]|, as float bits (one block per output channel)
+__global__ void l1norm_max_kernel(const float *__restrict__ w, int kind, int cin, int cout, int kk, unsigned *__restrict__ out) {
+    __shared__ float part[4];
+    const int co = blockIdx.x;
+    float a = 0.0f;
+    for (int i = threadIdx.x; i < cin * kk; i += blockDim.x) {
+        int ci = i / kk, t = i - ci * kk;
+        int64_t src = (kind == MPC_CONV) ? ((int64_t)co * cin + ci) * kk + t : ((int64_t)ci * cout + co) * kk + t;
+        a += fabsf(w[src]);
+    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(part[0] + part[1] + part[2] + part[3]));
+}
+
+// f16x3 GDN: gamma_eff * scale as fp16 hi/lo in the k order of the accumulator registers:
+// out[c'][(((f*2 + s)*2 + h)*2 + part)*8 + jj] <- gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
+__global__ void pack_gamma_x3_kernel(const float *__restrict__ gamma_eff, int cout, float scale, _Float16 *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cout * cout * 2) return;
+    int cp = i / (cout * 2), r = i % (cout * 2);
+    int jj = r & 7, part = (r >> 3) & 1, hh = (r >> 4) & 1, s = (r >> 5) & 1, f = r >> 6;
+    int c = 32 * f + 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+    float v = gamma_eff[(int64_t)cp * cout + c] * scale;
+    _Float16 hi = (_Float16)v;
+    out[i] = part ? (_Float16)(v - (float)hi) : hi;
+}
+
 // f16x3 weights: chunk = 1 tap x 32 input channels, image [kstep 2][h 2][hi|lo][cout_pad][8] fp16 of w * scale
 __global__ void pack_weights_x3_kernel(const PackDesc d, const float *__restrict__ w, float scale,
                                        _Float16 *__restrict__ out, int64_t total) {
@@ -382,9 +415,16 @@ __global__ void pack_weights_x3_kernel(const PackDesc d, const float *__restrict
     int row = (r >> 3) % d.cout_pad;
     int sl = (r >> 3) / d.cout_pad;       // (ks*2 + h)*2 + part
     int part = sl & 1, hh = (sl >> 1) & 1, ks = sl >> 2;
-    int cb = d.cin / 32;
-    int tap = chunk / cb;
-    int ci = (chunk % cb) * 32 + ks * 16 + hh * 8 + jj;
+    int tap, ci;
+    if (d.cin4) {                          // first layer: K axis = tap*cin + c, one pseudo-tap
+        int k = chunk * 32 + ks * 16 + hh * 8 + jj;
+        tap = k / d.cin;
+        ci = k - tap * d.cin;
+    } else {
+        int cb = d.cin / 32;
+        tap = chunk / cb;
+        ci = (chunk % cb) * 32 + ks * 16 + hh * 8 + jj;
+    }
     int co = group * d.cout_pad + row;
     float v = 0.0f;
     if (tap < d.ntaps[phase] && ci < d.cin && co < d.cout) {
@@ -446,8 +486,8 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     const bool f16 = (d.flags & MPC_F16) != 0;
     const bool x3 = (d.flags & MPC_F16X3) != 0;
     MPC_REQUIRE(ctx, !(x3 && f16), "conv_create: MPC_F16 and MPC_F16X3 are exclusive");
-    MPC_REQUIRE(ctx, !x3 || (!cin4 && !stacked && d.cin % 32 == 0 && (d.flags & MPC_IN_ABS) == 0),
-                "conv_create: the f16x3 path needs cin % 32 == 0, cout % 32 == 0 and no MPC_IN_ABS");
+    MPC_REQUIRE(ctx, !x3 || (!stacked && (cin4 ? d.cin == 3 : d.cin % 32 == 0) && (d.flags & MPC_IN_ABS) == 0),
+                "conv_create: the f16x3 path needs cin == 3 or cin % 32 == 0, cout % 32 == 0 and no MPC_IN_ABS");
     MPC_REQUIRE(ctx, !x3 || d.act == MPC_ACT_NONE || d.act == MPC_ACT_RELU || d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN,
                 "conv_create: the f16x3 path supports no activation, ReLU, GDN and IGDN");
     MPC_REQUIRE(ctx, !f16 || (!cin4 && d.cin % 64 == 0), "conv_create: the fp16 path needs cin to be a multiple of 64");
@@ -512,7 +552,8 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     c->nphase = pd.nphase;
     int64_t w_total = 0;
     for (int ph = 0; ph < pd.nphase; ++ph) {
-        pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
+        pd.nchunks[ph] = (cin4 && x3) ? (pd.ntaps[ph] * d.cin + 31) / 32
+                          : cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
         pd.w_off[ph] = w_total;
         w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * ((f16 || x3) ? 64 : 32);
         c->ph[ph].ntaps = pd.ntaps[ph]; c->ph[ph].nchunks = pd.nchunks[ph];
@@ -565,6 +606,34 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         if ((e = hipMalloc((void **)&c->gamma, sizeof(float) * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma)");
         gdn_reparam_kernel<<<dim3((unsigned)mpc_cdiv(d.cout, 256)), dim3(256), 0, ctx->stream>>>(beta, d.cout, beta_bound, pedestal, c->beta);
         gdn_reparam_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>(gamma, (int64_t)d.cout * d.cout, gamma_bound, pedestal, (float *)c->gamma);
+        if (x3 && d.in_bound > 0.0f) {
+            // split-precision GDN: bound |conv output| by in_bound * max_co sum|w| + max|b| to scale y^2 into fp16
+            unsigned *tmp = nullptr, host[3] = {0, 0, 0};
+            const int kk = d.ksize * d.ksize;
+            if ((e = hipMalloc((void **)&tmp, 3 * sizeof(unsigned))) != hipSuccess) return fail("hipMalloc(bounds)");
+            (void)hipMemsetAsync(tmp, 0, 3 * sizeof(unsigned), ctx->stream);
+            l1norm_max_kernel<<<dim3((unsigned)d.cout), dim3(256), 0, ctx->stream>>>(weight, d.kind, d.cin, d.cout, kk, tmp);
+            absmax_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(bias, d.cout, tmp + 1);
+            absmax_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>((const float *)c->gamma, (int64_t)d.cout * d.cout, tmp + 2);
+            e = hipMemcpyAsync(host, tmp, sizeof(host), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return fail("gdn bounds");
+            float l1, bmax, gmax;
+            memcpy(&l1, &host[0], 4); memcpy(&bmax, &host[1], 4); memcpy(&gmax, &host[2], 4);
+            const float ybound = d.in_bound * l1 + bmax;
+            int ey = 0, eg = 0;
+            (void)frexpf(ybound * ybound, &ey);                       // y^2 < 2^ey
+            if (gmax > 0.0f) (void)frexpf(gmax, &eg);
+            const int sy = 15 - ey;                                    // y^2 * 2^sy < 2^15
+            if (ybound > 0.0f && gmax > 0.0f && sy >= -20 && sy <= 20) {
+                c->y2_scale = ldexpf(1.0f, sy);
+                c->gamma_scale = ldexpf(1.0f, 14 - eg);
+                if ((e = hipMalloc(&c->gamma_x3, sizeof(_Float16) * 2 * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma x3)");
+                pack_gamma_x3_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)2 * d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>(
+                    (const float *)c->gamma, d.cout, c->gamma_scale, (_Float16 *)c->gamma_x3);
+            }
+        }
         if (f16) {
             void *g16 = nullptr;
             if ((e = hipMalloc(&g16, sizeof(_Float16) * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma f16)");
@@ -583,6 +652,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
 int mpc_conv_destroy(mpc_conv *c) {
     if (!c) return MPC_OK;
     (void)hipFree(c->wpk); (void)hipFree(c->bias); (void)hipFree(c->beta); (void)hipFree(c->gamma); (void)hipFree(c->taps);
+    (void)hipFree(c->gamma_x3);
     delete c;
     return MPC_OK;
 }
@@ -631,8 +701,11 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
     if (c->x3) {
         MPC_REQUIRE(ctx, !(flags & (MPC_OUT_NCHW | MPC_OUT_CLAMP01)), "conv_forward: the f16x3 path writes NHWC fp32 or the split format only");
         MPC_REQUIRE(ctx, !((flags & MPC_OUT_SPLIT) && want_round), "conv_forward: rounding needs the fp32 output");
-        p.cin_blocks = d.cin / 32;
+        p.cin_blocks = c->cin4 ? 1 : d.cin / 32;
         p.x3_unscale = 1.0f / (c->w_scale * X3_ACT_SCALE);
+        p.gamma_x3 = c->gamma_x3;
+        p.y2_scale = c->gamma_x3 ? c->y2_scale : 0.0f;
+        p.gdn_unscale = c->gamma_x3 ? 1.0f / (c->gamma_scale * c->y2_scale) : 0.0f;
         return mpc_conv_launch_x3(ctx, p, c);
     }
     MPC_REQUIRE(ctx, !(flags & MPC_OUT_SPLIT) || (gdn && !c->f16), "conv_forward: MPC_OUT_SPLIT is available on fp32 GDN layers and f16x3 layers");

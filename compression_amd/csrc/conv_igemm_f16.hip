@@ -144,9 +144,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
                 acc[f][4 * g + 2] += bb.z;
                 acc[f][4 * g + 3] += bb.w;
             }
-        _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
         if constexpr (EPI == EPI_GDN) {
             const bool inverse = p.act == MPC_ACT_IGDN;
+            // outputs go through the wave-private transposing store (2 bytes per element: 192 channels per round)
+            TransStore ts;
+            ts.init((char *)lds, wave, lane, j, h,
+                    pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
 #pragma unroll 1
             for (int fo = 0; fo < NF; ++fo) {
                 f32x16 nrm;
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
                     if (f == fo) yv = acc[f];
-                if (pvalid) {
+                {
+                    const int rbase = (fo % 6) * 64;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         int c0 = 32 * fo + 8 * g + 4 * h;
@@ -184,12 +188,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
                             float y = yv[4 * g + t];
                             o[t] = sat_half(inverse ? y * n : y / n);
                         }
-                        *(half4 *)(orow + c0) = o;
+                        *(half4 *)ts.at(j, rbase + (8 * g + 4 * h) * 2) = o;
                     }
+                    if (fo % 6 == 5 || fo == NF - 1)
+                        ts.flush((char *)p.out, (long long)COUT * 2, (fo / 6) * TS_ROW_BYTES, (fo % 6 + 1) * 64);
                 }
             }
         } else {
             if (!pvalid) return;
+            _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -211,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
 template <int NF, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase) {
     size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
+    if (EPI == EPI_GDN && lds < (size_t)TS_BLOCK_BYTES) lds = TS_BLOCK_BYTES;
     auto kern = conv_igemm_f16_kernel<NF, EPI>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {

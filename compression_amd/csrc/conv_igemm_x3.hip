@@ -40,7 +40,9 @@ __device__ __forceinline__ void split_store4(_Float16 *blk, int off, const float
     *(half4 *)(blk + 8 + off) = lo;
 }
 
-template <int NF, int EPI>
+// RGB = first layer: the input is the fp32 NHWC image padded to 4 channels; the K axis is the im2col index
+// k = tap*3 + c (75 real values padded to 96 = 3 chunks), gathered and split on the fly.
+template <int NF, int EPI, bool RGB>
 __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     constexpr int COUT = NF * 32;
     constexpr int CHUNK_F4 = COUT * 8;                    // 16-byte slots per weight chunk (2*2*2*COUT)
@@ -67,21 +69,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs * 2;
 
     auto load_b = [&](int chunk, float4 (&dst)[4]) {      // [ks][hi|lo]
-        int tap = chunk / p.cin_blocks;
-        int cb = chunk - tap * p.cin_blocks;
-        int2 d = taps[tap];
-        int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
-        bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
-        const _Float16 *src = in_b + ((int64_t)iy * p.Wi + ix) * p.Cs * 2 + (cb * 4 + h) * 16;
+        if constexpr (RGB) {
+            const float *img = (const float *)p.in + (int64_t)b * p.Hi * p.Wi * 4;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), vl = vh;
-            if (ok) {
-                vh = *(const float4 *)(src + ks * 32);
-                vl = *(const float4 *)(src + ks * 32 + 8);
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 vh, vl;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    int k = chunk * 32 + ks * 16 + h * 8 + jj;
+                    int tap = k / 3, c = k - tap * 3;
+                    float v = 0.0f;
+                    if (pvalid && tap < ph.ntaps) {
+                        int2 d = taps[tap];
+                        int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
+                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) v = img[((int64_t)iy * p.Wi + ix) * 4 + c];
+                    }
+                    v *= X3_ACT_SCALE;
+                    _Float16 hh = (_Float16)v;
+                    vh[jj] = hh;
+                    vl[jj] = (_Float16)(v - (float)hh);
+                }
+                dst[2 * ks] = __builtin_bit_cast(float4, vh);
+                dst[2 * ks + 1] = __builtin_bit_cast(float4, vl);
             }
-            dst[2 * ks] = vh;
-            dst[2 * ks + 1] = vl;
+        } else {
+            int tap = chunk / p.cin_blocks;
+            int cb = chunk - tap * p.cin_blocks;
+            int2 d = taps[tap];
+            int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
+            bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            const _Float16 *src = in_b + ((int64_t)iy * p.Wi + ix) * p.Cs * 2 + (cb * 4 + h) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float4 vh = make_float4(0.f, 0.f, 0.f, 0.f), vl = vh;
+                if (ok) {
+                    vh = *(const float4 *)(src + ks * 32);
+                    vl = *(const float4 *)(src + ks * 32 + 8);
+                }
+                dst[2 * ks] = vh;
+                dst[2 * ks + 1] = vl;
+            }
         }
     };
     const float4 *wsrc = (const float4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group + ph.w_off);
@@ -151,24 +178,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
 
     if constexpr (EPI == EPI_GDN) {
         const bool inverse = p.act == MPC_ACT_IGDN;
+        // outputs go through the wave-private transposing store (4 bytes per element: 96 channels per round)
+        TransStore ts;
+        ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
+        const long long pixel_bytes = (long long)COUT * 4;
 #pragma unroll 1
         for (int fo = 0; fo < NF; ++fo) {
             f32x16 nrm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
-            const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
+            if (p.y2_scale > 0.0f) {
+                // split-precision channel mix: gamma = g_hi + g_lo (scaled), y^2 = q_hi + q_lo (scaled), three
+                // fp16 MFMAs; k order of the accumulator registers: c = 32f + 16s + 8(jj>>2) + 4h + (jj&3)
+                const float4 *grow = (const float4 *)((const _Float16 *)p.gamma_x3 + (int64_t)(32 * fo + j) * COUT * 2) + h * 2;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                float4 ga[4];
+                for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) ga[g] = *(const float4 *)(grow + 32 * f + 8 * g);
+                    for (int s = 0; s < 2; ++s) {
+                        const half8 ah = as_half8(grow[(f * 2 + s) * 4]);
+                        const half8 al = as_half8(grow[(f * 2 + s) * 4 + 1]);
+                        half8 bh, bl;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float av[4] = {ga[g].x, ga[g].y, ga[g].z, ga[g].w};
+                        for (int jj = 0; jj < 8; ++jj) {
+                            float y = acc[f][8 * s + jj];
+                            float q = fminf(y * y * p.y2_scale, 65504.0f);
+                            _Float16 hh = (_Float16)q;
+                            bh[jj] = hh;
+                            bl[jj] = (_Float16)(q - (float)hh);
+                        }
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm, 0, 0, 0);
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm, 0, 0, 0);
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm, 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float y = acc[f][4 * g + t];
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], y * y, nrm, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) nrm[r] *= p.gdn_unscale;
+            } else {
+                const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    float4 ga[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) ga[g] = *(const float4 *)(grow + 32 * f + 8 * g);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float av[4] = {ga[g].x, ga[g].y, ga[g].z, ga[g].w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float y = acc[f][4 * g + t];
+                            nrm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], y * y, nrm, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -176,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
 #pragma unroll
             for (int f = 0; f < NF; ++f)
                 if (f == fo) yv = acc[f];
-            if (pvalid) {
+            {
+                const int rbase = (fo % 3) * 128;             // byte offset of this tile inside the round's row
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int c0 = 32 * fo + 8 * g + 4 * h;
@@ -190,13 +249,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
                         o[t] = inverse ? y * n : y / n;
                     }
                     if (out_split) {
+                        // block g of the tile: [hi x8 | lo x8]; this lane half owns elements 4h..4h+3 of each
+                        half4 hi4, lo4;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) o[t] *= X3_ACT_SCALE;
-                        split_store4((_Float16 *)p.out + (opix * COUT + (c0 & ~7)) * 2, c0 & 7, o);
+                        for (int t = 0; t < 4; ++t) {
+                            float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
+                            _Float16 hh = (_Float16)sv;
+                            hi4[t] = hh;
+                            lo4[t] = (_Float16)(sv - (float)hh);
+                        }
+                        *(half4 *)ts.at(j, rbase + g * 32 + 8 * h) = hi4;
+                        *(half4 *)ts.at(j, rbase + g * 32 + 16 + 8 * h) = lo4;
                     } else {
-                        *(float4 *)((float *)p.out + opix * COUT + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                        *(float4 *)ts.at(j, rbase + (8 * g + 4 * h) * 4) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
+                if (fo % 3 == 2 || fo == NF - 1) ts.flush((char *)p.out, pixel_bytes, (fo / 3) * TS_ROW_BYTES, (fo % 3 + 1) * 128);
             }
         }
     } else {
@@ -228,10 +296,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     }
 }
 
-template <int NF, int EPI>
+template <int NF, int EPI, bool RGB>
 int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
     size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
-    auto kern = conv_igemm_x3_kernel<NF, EPI>;
+    if (EPI == EPI_GDN && lds < (size_t)TS_BLOCK_BYTES) lds = TS_BLOCK_BYTES;
+    auto kern = conv_igemm_x3_kernel<NF, EPI, RGB>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -249,12 +318,17 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
     const int np = c->nphase, ng = c->groups;
-    if (gdn) {
-        if (c->nf == 4) return launch<4, EPI_GDN>(ctx, p, np, ng);
-        if (c->nf == 6) return launch<6, EPI_GDN>(ctx, p, np, ng);
+    if (c->cin4) {
+        if (gdn && c->nf == 4) return launch<4, EPI_GDN, true>(ctx, p, np, ng);
+        if (gdn && c->nf == 6) return launch<6, EPI_GDN, true>(ctx, p, np, ng);
+        if (!gdn && c->nf == 4) return launch<4, EPI_PLAIN, true>(ctx, p, np, ng);
+        if (!gdn && c->nf == 6) return launch<6, EPI_PLAIN, true>(ctx, p, np, ng);
+    } else if (gdn) {
+        if (c->nf == 4) return launch<4, EPI_GDN, false>(ctx, p, np, ng);
+        if (c->nf == 6) return launch<6, EPI_GDN, false>(ctx, p, np, ng);
     } else {
-        if (c->nf == 4) return launch<4, EPI_PLAIN>(ctx, p, np, ng);
-        if (c->nf == 6) return launch<6, EPI_PLAIN>(ctx, p, np, ng);
+        if (c->nf == 4) return launch<4, EPI_PLAIN, false>(ctx, p, np, ng);
+        if (c->nf == 6) return launch<6, EPI_PLAIN, false>(ctx, p, np, ng);
     }
     MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16x3): unsupported layer shape (cout/32 = %d)", c->nf);
 }

@@ -355,12 +355,32 @@ __global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, con
     const uint32_t M = (uint32_t)g.M;
     const int64_t prior_stride = (int64_t)g.M * g.L;
 
-    // Row address of symbol i (clamped to the stream so that prefetches past the end stay in bounds).
-    auto row_of = [&](uint32_t i) -> const uint16_t * {
-        uint32_t ii = i < e ? i : e - 1;
-        int k = img_idx[ii / M];
-        k = (k < 0 || k >= g.K) ? 0 : k;
-        return table + (int64_t)k * prior_stride + (int64_t)(ii % M) * g.L;
+    // Prefetch cursor: walks the rows of symbols b, b+1, ... (three ahead of the decode position).  The prior
+    // index of a location is read one whole location (M symbols) before its rows are needed, so no row address
+    // ever waits on an index load.
+    const uint32_t loc_last = (e - 1) / M;                 // valid when b < e
+    uint32_t pf_loc = b / M, pf_c = b % M;
+    auto clamp_k = [&](int k) { return (k < 0 || k >= g.K) ? 0 : k; };
+    int pf_k = (b < e) ? clamp_k(img_idx[pf_loc]) : 0;
+    int pf_knext = (b < e && pf_loc < loc_last) ? clamp_k(img_idx[pf_loc + 1]) : pf_k;
+    const uint16_t *pf_row = table + (int64_t)pf_k * prior_stride + (int64_t)pf_c * g.L;
+    uint32_t pf_i = b;
+    // returns the row of the cursor's symbol and advances the cursor (stays on the last symbol at the end)
+    auto next_row = [&]() -> const uint16_t * {
+        const uint16_t *r = pf_row;
+        if (pf_i + 1 < e) {
+            ++pf_i;
+            if (++pf_c == M) {
+                pf_c = 0;
+                ++pf_loc;
+                pf_k = pf_knext;
+                pf_knext = (pf_loc < loc_last) ? clamp_k(img_idx[pf_loc + 1]) : pf_k;
+                pf_row = table + (int64_t)pf_k * prior_stride;
+            } else {
+                pf_row += g.L;
+            }
+        }
+        return r;
     };
     auto stage = [&](int slot, const RowRegs &r) {
         uint4 *d = (uint4 *)&rows_sh[gi][slot][16 * t];
@@ -406,22 +426,22 @@ __global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, con
         if (__ballot(err != 0) >> gshift & 0xffffu) err = -23;
     }
     if (!err && b < e) {
-        RowRegs ra = load_row(row_of(b), t);
-        RowRegs rb = load_row(row_of(b + 1), t);
+        RowRegs ra = load_row(next_row(), t);
+        RowRegs rb = load_row(next_row(), t);
         stage(0, ra);
-        ra = load_row(row_of(b + 2), t);
+        ra = load_row(next_row(), t);
         uint32_t i = b;
         // invariant at the top: LDS slot (i-b)&3 holds row i; rb holds row i+1; ra holds row i+2
         while (i < e) {
             int s0 = (int)((i - b) & (RING - 1));
             stage((s0 + 1) & (RING - 1), rb);
-            rb = load_row(row_of(i + 3), t);
+            rb = load_row(next_row(), t);
             if (!decode_one(i, s0)) break;
             ++i;
             if (i >= e) break;
             int s1 = (int)((i - b) & (RING - 1));
             stage((s1 + 1) & (RING - 1), ra);
-            ra = load_row(row_of(i + 3), t);
+            ra = load_row(next_row(), t);
             if (!decode_one(i, s1)) break;
             ++i;
         }

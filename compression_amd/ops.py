@@ -309,7 +309,7 @@ class ConvLayer:
 
     def __init__(self, kind: int, weight: torch.Tensor, bias: torch.Tensor, ksize: int, stride: int, act: int = 0,
                  beta: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None, in_abs: bool = False,
-                 f16: bool = False, x3: bool = False):
+                 f16: bool = False, x3: bool = False, in_bound: float = 0.0):
         w = _dev(weight.detach().contiguous(), torch.float32, "weight")
         b = _dev(bias.detach().contiguous(), torch.float32, "bias")
         if kind == _lib.MPC_CONV:
@@ -327,7 +327,7 @@ class ConvLayer:
         self.desc = ConvDesc(kind, cin, cout, ksize, stride, (ksize - 1) // 2,
                              stride - 1 if kind == _lib.MPC_DECONV else 0, act,
                              (_lib.MPC_IN_ABS if in_abs else 0) | (_lib.MPC_F16 if f16 else 0) |
-                             (_lib.MPC_F16X3 if x3 else 0))
+                             (_lib.MPC_F16X3 if x3 else 0), float(in_bound))
         self.f16, self.x3 = f16, x3
         self.device = w.device
         self.cin, self.cout, self.kind, self.stride, self.ksize = cin, cout, kind, stride, ksize
@@ -338,7 +338,7 @@ class ConvLayer:
         tiles = 1 if self.small_cout else cout // 32
         nf = tiles // (2 if tiles > 6 else 1)
         epi = 2 if self.small_cout else (1 if gdn else 0)
-        self.kernel_name = ("conv_igemm_x3_kernel<%d, %d>" % (nf, epi)) if x3 else \
+        self.kernel_name = ("conv_igemm_x3_kernel<%d, %d, %s>" % (nf, epi, "true" if cin <= 4 else "false")) if x3 else \
             ("conv_igemm_f16_kernel<%d, %d>" % (nf, epi)) if f16 else \
             ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
         ctx = context_for(w.device)
@@ -359,8 +359,10 @@ class ConvLayer:
         (the small-cout RGB layer always returns fp32 NCHW; out_split returns an S16 tensor [B,Ho,Wo,cout/8,16]);
         with round_out returns (unrounded | None, rounded)."""
         adt = torch.float16 if (self.f16 or self.x3) else torch.float32
+        if self.x3 and self.cin <= 4:
+            adt = torch.float32
         _dev(x, adt, "x")
-        if self.x3:
+        if self.x3 and self.cin > 4:
             if x.dim() != 5 or x.shape[3] * 8 != self.cin or x.shape[4] != 16:
                 raise MpcError(f"f16x3 layer expects a split tensor [B,H,W,{self.cin // 8},16], got {tuple(x.shape)}")
             B, H, W = x.shape[:3]

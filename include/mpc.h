@@ -167,6 +167,9 @@ typedef struct {
     int32_t out_pad;  /* stride-1 for MPC_DECONV, else 0 */
     int32_t act;      /* MPC_ACT_* applied to (conv + bias) */
     int32_t flags;    /* MPC_IN_ABS | MPC_F16 | MPC_F16X3 */
+    float in_bound;   /* MPC_F16X3 with GDN/IGDN: an upper bound of |input| (1 for an image in [0,1],
+                         1/sqrt(min_i gamma_ii) after a GDN).  > 0 lets the channel mix run on the split-precision
+                         fp16 MFMA as well; 0 keeps it on the exact f32 MFMA. */
 } mpc_conv_desc;
 
 /* Builds one layer from PyTorch-layout device tensors: weight [cout,cin,k,k] (MPC_CONV) or

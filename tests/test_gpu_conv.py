@@ -216,7 +216,8 @@ def test_split_precision_layer_is_fp32_grade(dev, ops, cout, gdn):
     act = _lib.MPC_ACT_GDN if gdn else _lib.MPC_ACT_NONE
     args = (beta.to(dev), gamma.to(dev)) if gdn else (None, None)
     l32 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, act, *args)
-    lx3 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, act, *args, x3=True)
+    # in_bound > 0 puts the GDN channel mix on the split-precision MFMA too
+    lx3 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, act, *args, x3=True, in_bound=float(x.abs().max()))
     xs = to_split(nhwc(x)).to(dev)
     x_rt = from_split(xs.cpu())                        # what the split format actually holds (22 bits)
     assert (x_rt - nhwc(x)).abs().max().item() < 1e-6
@@ -234,3 +235,27 @@ def test_split_precision_layer_is_fp32_grade(dev, ops, cout, gdn):
         outs32 = l32(nhwc(x).to(dev), out_split=True)
         back32 = from_split(outs32.cpu()).permute(0, 3, 1, 2).double()
         assert ((back32 - ref).abs().max() / ref.abs().max()).item() < 5e-6
+
+
+def test_split_precision_first_layer_rgb(dev, ops):
+    """conv1 (3 -> 192, 5x5 s2) + GDN on the split-precision path: the im2col K axis (75 -> 96) is gathered from
+    the padded NHWC image on the fly."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 34, 50, generator=g)
+    w, b = _w(g, 192, 3, 5, 5, scale=0.3), _w(g, 192)
+    beta, gamma = synth._gdn(g, 192)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+    be, ga = O.gdn_effective(beta, gamma)
+    ref = ref / torch.sqrt(F.conv2d(ref ** 2, ga.double().view(192, 192, 1, 1), be.double()))
+    x4 = ops.nchw_to_nhwc(x.to(dev), 4)
+    l32 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_GDN, beta.to(dev), gamma.to(dev))
+    lx3 = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_GDN, beta.to(dev), gamma.to(dev),
+                        x3=True, in_bound=1.0)
+    e32 = ((l32(x4).cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()).item()
+    got = lx3(x4)
+    ex3 = ((got.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()).item()
+    gots = from_split(lx3(x4, out_split=True).cpu()).permute(0, 3, 1, 2).double()
+    exs = ((gots - ref).abs().max() / ref.abs().max()).item()
+    print(f"first layer: rel err vs fp64  f32-MFMA {e32:.2e}   f16x3 {ex3:.2e}   f16x3 split-out {exs:.2e}")
+    assert ex3 < 3e-6 and exs < 3e-6
