@@ -19,7 +19,7 @@ MPC_BITS_LOG2 = 0
 MPC_BITS_LN = 1
 MPC_CONV, MPC_DECONV = 0, 1
 MPC_ACT_NONE, MPC_ACT_GDN, MPC_ACT_IGDN, MPC_ACT_RELU, MPC_ACT_EXP = 0, 1, 2, 3, 4
-MPC_IN_ABS, MPC_OUT_ROUND, MPC_OUT_CLAMP01, MPC_OUT_NCHW, MPC_F16, MPC_F16X3, MPC_OUT_SPLIT = 1, 2, 4, 8, 16, 32, 128
+MPC_IN_ABS, MPC_OUT_ROUND, MPC_OUT_CLAMP01, MPC_OUT_NCHW, MPC_F16, MPC_F16X3, MPC_WIDE_BLOCK, MPC_OUT_SPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class MpcError(RuntimeError):

@@ -11,6 +11,19 @@ constexpr int PIX_PER_BLOCK = 32 * WAVES;
 
 enum { EPI_PLAIN = 0, EPI_GDN = 1, EPI_STACKED = 2 };
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and every XCD has its own L2.  The
+// grid's x extent is rounded up to a multiple of 8 and block x is remapped so that XCD c works on
+// the c-th contiguous eighth of the pixel blocks: neighbouring pixels, which share most of their
+// input taps, then meet in one L2 instead of being fetched by all eight.
+constexpr int NUM_XCD = 8;
+inline int64_t xcd_grid(int64_t blocks) { return (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD; }
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t xcd_block() {
+    const unsigned per = gridDim.x / NUM_XCD;
+    return (int64_t)(blockIdx.x % NUM_XCD) * per + blockIdx.x / NUM_XCD;
+}
+#endif
+
 // Power-of-two scale of activations stored in the split-fp16 ("S16") format.
 constexpr float X3_ACT_SCALE = 256.0f;
 
@@ -85,6 +98,15 @@ struct TransStore {
         }
     }
 };
+
+// The fp16 / f16x3 kernels come with 4 or 8 waves (128 or 256 pixels) per workgroup.  A workgroup stages
+// every weight chunk once for all of its waves, and the weight traffic is most of what goes through the
+// CU's vector-memory path, so one 8-wave workgroup per CU moves a third less data than two 4-wave
+// workgroups.  Used once there are at least two 256-pixel workgroups per CU (or forced by MPC_WIDE_BLOCK).
+constexpr int NUM_CU = 256;
+inline bool wide_blocks(const Params &p, int launches_per_pixel_block) {
+    return (p.flags & MPC_WIDE_BLOCK) || (p.P + 255) / 256 * launches_per_pixel_block >= 2 * NUM_CU;
+}
 
 // Layer object behind the opaque mpc_conv handle.
 struct mpc_conv {

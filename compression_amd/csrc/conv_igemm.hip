@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
     const int2 *taps = p.taps + ph.tap_off;
     const int cg = blockIdx.z * COUT;                     // first output channel of this block's cout group
 
-    const int64_t pix = (int64_t)blockIdx.x * PIX_PER_BLOCK + wave * 32 + j;
+    const int64_t blk = xcd_block();
+    if (blk * PIX_PER_BLOCK >= p.P) return;           // padding block of the rounded-up grid
+    const int64_t pix = blk * PIX_PER_BLOCK + wave * 32 + j;
     const bool pvalid = pix < p.P;
     int b = 0, by = 0, bx = 0;
     if (pvalid) {
@@ -416,10 +418,10 @@ __global__ void pack_weights_x3_kernel(const PackDesc d, const float *__restrict
     int sl = (r >> 3) / d.cout_pad;       // (ks*2 + h)*2 + part
     int part = sl & 1, hh = (sl >> 1) & 1, ks = sl >> 2;
     int tap, ci;
-    if (d.cin4) {                          // first layer: K axis = tap*cin + c, one pseudo-tap
+    if (d.cin4) {                          // first layer: K axis = tap*4 + c (8 taps of the padded pixel per chunk)
         int k = chunk * 32 + ks * 16 + hh * 8 + jj;
-        tap = k / d.cin;
-        ci = k - tap * d.cin;
+        tap = k >> 2;
+        ci = k & 3;
     } else {
         int cb = d.cin / 32;
         tap = chunk / cb;
@@ -460,7 +462,7 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    int64_t bx = mpc_cdiv(p.P, PIX_PER_BLOCK);
+    int64_t bx = xcd_grid(mpc_cdiv(p.P, PIX_PER_BLOCK));
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
     kern<<<dim3((unsigned)bx, (unsigned)nphase, (unsigned)groups), dim3(256), lds, ctx->stream>>>(p);
     MPC_CHECK_LAUNCH(ctx, "conv_igemm");
@@ -552,8 +554,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     c->nphase = pd.nphase;
     int64_t w_total = 0;
     for (int ph = 0; ph < pd.nphase; ++ph) {
-        pd.nchunks[ph] = (cin4 && x3) ? (pd.ntaps[ph] * d.cin + 31) / 32
-                          : cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
+        pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
         pd.w_off[ph] = w_total;
         w_total += (int64_t)pd.nchunks[ph] * pd.cout_pad * ((f16 || x3) ? 64 : 32);
         c->ph[ph].ntaps = pd.ntaps[ph]; c->ph[ph].nchunks = pd.nchunks[ph];

@@ -31,11 +31,12 @@ __device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bi
 
 __device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -HALF_MAX), HALF_MAX); }
 
-template <int NF, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) {
+template <int NF, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params p) {
     constexpr int COUT = NF * 32;
     constexpr int CHUNK_F4 = COUT * 8;                    // 16-byte slots per weight chunk (Cout x 64 halfs)
-    constexpr int STAGE = CHUNK_F4 / 256;
+    constexpr int NT = 64 * NW;                           // threads per block (NW waves of 32 pixels)
+    constexpr int STAGE = CHUNK_F4 / NT;
     extern __shared__ float4 lds[];                       // 2 x CHUNK_F4
 
     const int tid = threadIdx.x;
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
     const Phase ph = p.ph[blockIdx.y];
     const int2 *taps = p.taps + ph.tap_off;
 
-    const int64_t pix = (int64_t)blockIdx.x * PIX_PER_BLOCK + wave * 32 + j;
+    const int64_t blk = xcd_block();
+    if (blk * (32 * NW) >= p.P) return;                 // padding block of the rounded-up grid
+    const int64_t pix = blk * (32 * NW) + wave * 32 + j;
     const bool pvalid = pix < p.P;
     int b = 0, by = 0, bx = 0;
     if (pvalid) {
@@ -73,12 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
     auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
         const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
 #pragma unroll
-        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * 256];
+        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * NT];
     };
     auto store_w = [&](int buf, const float4 (&src)[STAGE]) {
         float4 *d = lds + buf * CHUNK_F4 + tid;
 #pragma unroll
-        for (int r = 0; r < STAGE; ++r) d[r * 256] = src[r];
+        for (int r = 0; r < STAGE; ++r) d[r * NT] = src[r];
     };
 
     f32x16 acc[NF];
@@ -150,6 +153,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
             TransStore ts;
             ts.init((char *)lds, wave, lane, j, h,
                     pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
+            // the B operand of the channel mix (scaled squares in fp16), built once for all output tiles
+            half8 q[NF][2];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        float y = acc[f][8 * s + jj];
+                        q[f][s][jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                    }
 #pragma unroll 1
             for (int fo = 0; fo < NF; ++fo) {
                 f32x16 nrm;
@@ -160,16 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const half8 av = as_half8(grow[(f * 2 + s) * 2]);
-                        half8 bv;
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) {
-                            float y = acc[f][8 * s + jj];
-                            bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
-                        }
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, nrm, 0, 0, 0);
-                    }
+                    for (int s = 0; s < 2; ++s)
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(grow[(f * 2 + s) * 2]), q[f][s], nrm, 0, 0, 0);
                 f32x16 yv;
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
@@ -215,21 +221,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16_kernel(const Params p) 
     }
 }
 
-template <int NF, int EPI>
-int launch(mpc_ctx *ctx, const Params &p, int nphase) {
+template <int NF, int EPI, int NW>
+int launch_nw(mpc_ctx *ctx, const Params &p, int nphase) {
     size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
-    if (EPI == EPI_GDN && lds < (size_t)TS_BLOCK_BYTES) lds = TS_BLOCK_BYTES;
-    auto kern = conv_igemm_f16_kernel<NF, EPI>;
+    if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    auto kern = conv_igemm_f16_kernel<NF, EPI, NW>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    int64_t bx = mpc_cdiv(p.P, PIX_PER_BLOCK);
+    int64_t bx = xcd_grid(mpc_cdiv(p.P, 32 * NW));
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
-    kern<<<dim3((unsigned)bx, (unsigned)nphase, 1), dim3(256), lds, ctx->stream>>>(p);
+    kern<<<dim3((unsigned)bx, (unsigned)nphase, 1), dim3(64 * NW), lds, ctx->stream>>>(p);
     MPC_CHECK_LAUNCH(ctx, "conv_igemm_f16");
     return MPC_OK;
+}
+
+template <int NF, int EPI>
+int launch(mpc_ctx *ctx, const Params &p, int nphase) {
+    if constexpr (NF >= 2) {                  // the one-tile weight chunk is too small to spread over 512 threads
+        if (wide_blocks(p, nphase)) return launch_nw<NF, EPI, 8>(ctx, p, nphase);
+    }
+    return launch_nw<NF, EPI, 4>(ctx, p, nphase);
 }
 
 }  // namespace

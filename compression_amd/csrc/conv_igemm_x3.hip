@@ -41,12 +41,14 @@ __device__ __forceinline__ void split_store4(_Float16 *blk, int off, const float
 }
 
 // RGB = first layer: the input is the fp32 NHWC image padded to 4 channels; the K axis is the im2col index
-// k = tap*3 + c (75 real values padded to 96 = 3 chunks), gathered and split on the fly.
-template <int NF, int EPI, bool RGB>
-__global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
+// k = tap*4 + c (8 taps per chunk, 25 taps -> 4 chunks; the weights of c = 3 and of the padding taps are
+// zero), gathered with one 16-byte load per tap and split on the fly.
+template <int NF, int EPI, bool RGB, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params p) {
     constexpr int COUT = NF * 32;
     constexpr int CHUNK_F4 = COUT * 8;                    // 16-byte slots per weight chunk (2*2*2*COUT)
-    constexpr int STAGE = CHUNK_F4 / 256;
+    constexpr int NT = 64 * NW;                           // threads per block (NW waves of 32 pixels)
+    constexpr int STAGE = CHUNK_F4 / NT;
     extern __shared__ float4 lds[];                       // 2 x CHUNK_F4
 
     const int tid = threadIdx.x;
@@ -55,7 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     const int2 *taps = p.taps + ph.tap_off;
     const int cg = blockIdx.z * COUT;
 
-    const int64_t pix = (int64_t)blockIdx.x * PIX_PER_BLOCK + wave * 32 + j;
+    const int64_t blk = xcd_block();
+    if (blk * (32 * NW) >= p.P) return;                 // padding block of the rounded-up grid
+    const int64_t pix = blk * (32 * NW) + wave * 32 + j;
     const bool pvalid = pix < p.P;
     int b = 0, by = 0, bx = 0;
     if (pvalid) {
@@ -70,24 +74,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
 
     auto load_b = [&](int chunk, float4 (&dst)[4]) {      // [ks][hi|lo]
         if constexpr (RGB) {
-            const float *img = (const float *)p.in + (int64_t)b * p.Hi * p.Wi * 4;
+            // k = tap*4 + c: the lane's 8 k-values of a k-step are two whole padded pixels (taps)
+            const float4 *img = (const float4 *)p.in + (int64_t)b * p.Hi * p.Wi;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    int tap = chunk * 8 + ks * 4 + h * 2 + t;
+                    int2 d = taps[tap < ph.ntaps ? tap : 0];
+                    int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
+                    bool ok = pvalid && tap < ph.ntaps && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                    float4 px = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) px = img[(int64_t)iy * p.Wi + ix];
+                    v[4 * t + 0] = px.x; v[4 * t + 1] = px.y; v[4 * t + 2] = px.z; v[4 * t + 3] = px.w;
+                }
                 half8 vh, vl;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    int k = chunk * 32 + ks * 16 + h * 8 + jj;
-                    int tap = k / 3, c = k - tap * 3;
-                    float v = 0.0f;
-                    if (pvalid && tap < ph.ntaps) {
-                        int2 d = taps[tap];
-                        int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
-                        if (iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) v = img[((int64_t)iy * p.Wi + ix) * 4 + c];
-                    }
-                    v *= X3_ACT_SCALE;
-                    _Float16 hh = (_Float16)v;
+                    float sv = v[jj] * X3_ACT_SCALE;
+                    _Float16 hh = (_Float16)sv;
                     vh[jj] = hh;
-                    vl[jj] = (_Float16)(v - (float)hh);
+                    vl[jj] = (_Float16)(sv - (float)hh);
                 }
                 dst[2 * ks] = __builtin_bit_cast(float4, vh);
                 dst[2 * ks + 1] = __builtin_bit_cast(float4, vl);
@@ -115,12 +123,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
         const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
 #pragma unroll
-        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * 256];
+        for (int r = 0; r < STAGE; ++r) dst[r] = s[r * NT];
     };
     auto store_w = [&](int buf, const float4 (&src)[STAGE]) {
         float4 *d = lds + buf * CHUNK_F4 + tid;
 #pragma unroll
-        for (int r = 0; r < STAGE; ++r) d[r * 256] = src[r];
+        for (int r = 0; r < STAGE; ++r) d[r * NT] = src[r];
     };
 
     f32x16 acc[NF];
@@ -296,21 +304,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_x3_kernel(const Params p) {
     }
 }
 
-template <int NF, int EPI, bool RGB>
-int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
+template <int NF, int EPI, bool RGB, int NW>
+int launch_nw(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
     size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
-    if (EPI == EPI_GDN && lds < (size_t)TS_BLOCK_BYTES) lds = TS_BLOCK_BYTES;
-    auto kern = conv_igemm_x3_kernel<NF, EPI, RGB>;
+    if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    auto kern = conv_igemm_x3_kernel<NF, EPI, RGB, NW>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    int64_t bx = mpc_cdiv(p.P, PIX_PER_BLOCK);
+    int64_t bx = xcd_grid(mpc_cdiv(p.P, 32 * NW));
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
-    kern<<<dim3((unsigned)bx, (unsigned)nphase, (unsigned)groups), dim3(256), lds, ctx->stream>>>(p);
+    kern<<<dim3((unsigned)bx, (unsigned)nphase, (unsigned)groups), dim3(64 * NW), lds, ctx->stream>>>(p);
     MPC_CHECK_LAUNCH(ctx, "conv_igemm_x3");
     return MPC_OK;
+}
+
+template <int NF, int EPI, bool RGB>
+int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
+    if (wide_blocks(p, nphase * groups)) return launch_nw<NF, EPI, RGB, 8>(ctx, p, nphase, groups);
+    return launch_nw<NF, EPI, RGB, 4>(ctx, p, nphase, groups);
 }
 
 }  // namespace

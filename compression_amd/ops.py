@@ -338,9 +338,11 @@ class ConvLayer:
         tiles = 1 if self.small_cout else cout // 32
         nf = tiles // (2 if tiles > 6 else 1)
         epi = 2 if self.small_cout else (1 if gdn else 0)
-        self.kernel_name = ("conv_igemm_x3_kernel<%d, %d, %s>" % (nf, epi, "true" if cin <= 4 else "false")) if x3 else \
-            ("conv_igemm_f16_kernel<%d, %d>" % (nf, epi)) if f16 else \
+        self._name_fmt = ("conv_igemm_x3_kernel<%d, %d, %s, %%d>" % (nf, epi, "true" if cin <= 4 else "false")) if x3 else \
+            ("conv_igemm_f16_kernel<%d, %d, %%d>" % (nf, epi)) if f16 else \
             ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
+        self._launches = (tiles // nf) * (4 if (kind == _lib.MPC_DECONV and stride == 2 and not self.small_cout) else 1)
+        self.kernel_name = self._name_fmt % 4 if (x3 or f16) else self._name_fmt
         ctx = context_for(w.device)
         h = c_void_p()
         ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
@@ -353,11 +355,12 @@ class ConvLayer:
         return ho.value, wo.value
 
     def __call__(self, x: torch.Tensor, nchw_out: bool = False, clamp01: bool = False, round_out: bool = False,
-                 keep_unrounded: bool = True, out_split: bool = False):
+                 keep_unrounded: bool = True, out_split: bool = False, wide_block: bool = False):
         """x: NHWC [B,H,W,cin (3 channels padded to 4)] fp32; fp16 for an f16 layer; the split-fp16 "S16" tensor
         [B,H,W,cin/8,16] fp16 for an f16x3 layer.  Returns NHWC (or NCHW) output of the layer's activation type
         (the small-cout RGB layer always returns fp32 NCHW; out_split returns an S16 tensor [B,Ho,Wo,cout/8,16]);
-        with round_out returns (unrounded | None, rounded)."""
+        with round_out returns (unrounded | None, rounded).  wide_block forces the 8-wave workgroups of the
+        fp16 / f16x3 kernels (normally chosen by problem size; same results)."""
         adt = torch.float16 if (self.f16 or self.x3) else torch.float32
         if self.x3 and self.cin <= 4:
             adt = torch.float32
@@ -373,7 +376,13 @@ class ConvLayer:
         Ho, Wo = self.out_hw(H, W)
         nchw_out = nchw_out or self.small_cout
         flags = (_lib.MPC_OUT_NCHW if nchw_out else 0) | (_lib.MPC_OUT_CLAMP01 if clamp01 else 0) | \
-                (_lib.MPC_OUT_ROUND if round_out else 0) | (_lib.MPC_OUT_SPLIT if out_split else 0)
+                (_lib.MPC_OUT_ROUND if round_out else 0) | (_lib.MPC_OUT_SPLIT if out_split else 0) | \
+                (_lib.MPC_WIDE_BLOCK if wide_block else 0)
+        if self.f16 or self.x3:
+            # mirrors the library's choice of waves per workgroup (for the kernel name in profiles)
+            base = B * (H * W if self.kind == _lib.MPC_DECONV else Ho * Wo)
+            wide = (wide_block or -(-base // 256) * self._launches >= 512) and not self.small_cout
+            self.kernel_name = self._name_fmt % (8 if wide else 4)
         if out_split:
             shape, odt = (B, Ho, Wo, self.cout // 8, 16), torch.float16
         else:

@@ -152,6 +152,8 @@ enum {
                               (4 bytes per element); the output is fp32 NHWC or, with MPC_OUT_SPLIT, S16. */
     MPC_OUT_SPLIT = 128,   /* forward flag: write the output in the S16 split format (fp32 GDN layers and
                               MPC_F16X3 layers), for a following MPC_F16X3 layer */
+    MPC_WIDE_BLOCK = 64,   /* forward flag (MPC_F16 / MPC_F16X3 layers): 8-wave (256-pixel) workgroups.  Chosen
+                              automatically for large inputs; the flag forces it.  Results are identical. */
     MPC_IN_ABS = 1,        /* take |x| of the input (Analysis_prior_net.forward, :123-124) */
     MPC_OUT_ROUND = 2,     /* also emit rint(out) (torch.round, manynets_compressor.py:533) */
     MPC_OUT_CLAMP01 = 4,   /* clamp(0,1) (manynets_compressor.py:537) */

@@ -169,18 +169,22 @@ def test_fp16_layers_against_fp32_reference(dev, ops, cin, act):
         want = O.gdn(F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1), beta, gamma, inverse=True)
         layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_IGDN, beta.to(dev), gamma.to(dev), f16=True)
         got = layer(xh).float().cpu().permute(0, 3, 1, 2)
+        got2 = layer(xh, wide_block=True).float().cpu().permute(0, 3, 1, 2)
     elif act == "relu_conv":
         w, b = _w(g, 192, cin, 5, 5), _w(g, 192)
         want = F.relu(F.conv2d(x, w, b, stride=1, padding=2))
         layer = ops.ConvLayer(_lib.MPC_CONV, w.to(dev), b.to(dev), 5, 1, _lib.MPC_ACT_RELU, f16=True)
         got = layer(xh).float().cpu().permute(0, 3, 1, 2)
+        got2 = layer(xh, wide_block=True).float().cpu().permute(0, 3, 1, 2)
     else:
         w, b = _w(g, cin, 3, 5, 5, scale=0.02), _w(g, 3, scale=0.5)
         want = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
         layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, f16=True)
         got = layer(xh).cpu()
+        got2 = layer(xh, wide_block=True).cpu()
         assert got.dtype == torch.float32
     assert got.shape == want.shape
+    assert torch.equal(got, got2), "8-wave workgroups must give identical results"
     err = rel_err(got, want)
     print(f"fp16 layer {act} cin={cin}: rel err {err:.2e}")
     assert err < 4e-3
@@ -223,6 +227,7 @@ def test_split_precision_layer_is_fp32_grade(dev, ops, cout, gdn):
     assert (x_rt - nhwc(x)).abs().max().item() < 1e-6
     got32 = l32(nhwc(x).to(dev)).cpu().permute(0, 3, 1, 2).double()
     gotx3 = lx3(xs).cpu().permute(0, 3, 1, 2).double()
+    assert torch.equal(lx3(xs, wide_block=True).cpu().permute(0, 3, 1, 2).double(), gotx3)
     e32 = ((got32 - ref).abs().max() / ref.abs().max()).item()
     ex3 = ((gotx3 - ref).abs().max() / ref.abs().max()).item()
     print(f"cout={cout} gdn={gdn}: rel err vs fp64  f32-MFMA {e32:.2e}   f16x3 {ex3:.2e}")
@@ -230,6 +235,7 @@ def test_split_precision_layer_is_fp32_grade(dev, ops, cout, gdn):
     # split output feeds the next layer: round trip through the S16 writer
     if gdn:
         outs = lx3(xs, out_split=True)
+        assert torch.equal(lx3(xs, out_split=True, wide_block=True), outs)
         back = from_split(outs.cpu()).permute(0, 3, 1, 2).double()
         assert ((back - ref).abs().max() / ref.abs().max()).item() < 5e-6
         outs32 = l32(nhwc(x).to(dev), out_split=True)
@@ -254,6 +260,7 @@ def test_split_precision_first_layer_rgb(dev, ops):
                         x3=True, in_bound=1.0)
     e32 = ((l32(x4).cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()).item()
     got = lx3(x4)
+    assert torch.equal(lx3(x4, wide_block=True), got)
     ex3 = ((got.cpu().permute(0, 3, 1, 2).double() - ref).abs().max() / ref.abs().max()).item()
     gots = from_split(lx3(x4, out_split=True).cpu()).permute(0, 3, 1, 2).double()
     exs = ((gots - ref).abs().max() / ref.abs().max()).item()
