@@ -88,13 +88,25 @@ struct TransStore {
     }
     // pointer to byte `off` of pixel j's row of the current round
     __device__ __forceinline__ char *at(int j, int off) const { return rows + j * TS_ROW_PAD + off; }
-    // write `nbytes` (multiple of 16) per pixel to out + opix*pixel_bytes + col_off
-    __device__ __forceinline__ void flush(char *out, long long pixel_bytes, int col_off, int nbytes) const {
-        const int pieces = nbytes >> 4, total = 32 * pieces;
+    // write `pieces` 16-byte pieces per pixel to out + opix*pixel_bytes + col_off
+    __device__ __forceinline__ void flush(char *out, long long pixel_bytes, int col_off, int pieces) const {
+        const int total = 32 * pieces;
         for (int i = lane; i < total; i += 64) {
             int px = i / pieces, pc = i - px * pieces;
             long long o = opix[px];
             if (o >= 0) *(float4 *)(out + o * pixel_bytes + col_off + pc * 16) = *(const float4 *)(rows + px * TS_ROW_PAD + pc * 16);
+        }
+    }
+    template <int PIECES>
+    __device__ __forceinline__ void flush(char *out, long long pixel_bytes, int col_off) const {
+#pragma unroll
+        for (int i0 = 0; i0 < 32 * PIECES; i0 += 64) {
+            const int i = i0 + lane;
+            const int px = i / PIECES, pc = i - px * PIECES;
+            if (i < 32 * PIECES) {
+                long long o = opix[px];
+                if (o >= 0) *(float4 *)(out + o * pixel_bytes + col_off + pc * 16) = *(const float4 *)(rows + px * TS_ROW_PAD + pc * 16);
+            }
         }
     }
 };

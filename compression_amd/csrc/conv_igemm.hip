@@ -351,14 +351,16 @@ __global__ void pack_weights_kernel(const PackDesc d, const float *__restrict__ 
     else ((float *)out)[i] = v;
 }
 
-// fp16 gamma in the operand order of the fused GDN MFMA: out[c'][((f*2 + s)*2 + h)*8 + jj] =
-// gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
+// fp16 gamma as cout/64 chunks in the weight-chunk layout of the fp16 kernel (chunk kc = 64 input channels of
+// the mix, 4 k-steps): out[kc][(ks*2 + h)*cout + c'][jj] <- gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
+// with f = 2kc + (ks>>1), s = ks&1: the k order of the accumulator registers
 __global__ void pack_gamma_f16_kernel(const float *__restrict__ gamma_eff, int cout, _Float16 *__restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cout * cout) return;
-    int cp = i / cout, r = i % cout;
-    int jj = r & 7, hh = (r >> 3) & 1, s = (r >> 4) & 1, f = r >> 5;
-    int c = 32 * f + 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+    int kc = i / (cout * 64), r = i % (cout * 64);
+    int jj = r & 7, cp = (r >> 3) % cout, sl = (r >> 3) / cout;
+    int hh = sl & 1, ks = sl >> 1;
+    int c = 32 * (2 * kc + (ks >> 1)) + 16 * (ks & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3);
     out[i] = (_Float16)gamma_eff[(int64_t)cp * cout + c];
 }
 
@@ -387,14 +389,16 @@ __global__ void l1norm_max_kernel(const float *__restrict__ w, int kind, int cin
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(part[0] + part[1] + part[2] + part[3]));
 }
 
-// f16x3 GDN: gamma_eff * scale as fp16 hi/lo in the k order of the accumulator registers:
-// out[c'][(((f*2 + s)*2 + h)*2 + part)*8 + jj] <- gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
+// f16x3 GDN: gamma_eff * scale as fp16 hi/lo, as cout/32 chunks in the weight-chunk layout of the f16x3 kernel
+// (chunk kc = 32 input channels of the mix): out[kc][((s*2 + h)*2 + part)*cout + c'][jj] <-
+// gamma_eff[c'][32kc + 16s + 8(jj>>2) + 4h + (jj&3)], the k order of the accumulator registers
 __global__ void pack_gamma_x3_kernel(const float *__restrict__ gamma_eff, int cout, float scale, _Float16 *__restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cout * cout * 2) return;
-    int cp = i / (cout * 2), r = i % (cout * 2);
-    int jj = r & 7, part = (r >> 3) & 1, hh = (r >> 4) & 1, s = (r >> 5) & 1, f = r >> 6;
-    int c = 32 * f + 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
+    int kc = i / (cout * 64), r = i % (cout * 64);
+    int jj = r & 7, cp = (r >> 3) % cout, sl = (r >> 3) / cout;
+    int part = sl & 1, hh = (sl >> 1) & 1, s = sl >> 2;
+    int c = 32 * kc + 16 * s + 8 * (jj >> 2) + 4 * hh + (jj & 3);
     float v = gamma_eff[(int64_t)cp * cout + c] * scale;
     _Float16 hi = (_Float16)v;
     out[i] = part ? (_Float16)(v - (float)hi) : hi;

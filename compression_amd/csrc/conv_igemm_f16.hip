@@ -73,8 +73,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
         }
     };
     const float4 *wsrc = (const float4 *)((const _Float16 *)p.wpk + ph.w_off);
-    auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
-        const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
+    // GDN: gamma is packed as NF/2 more "weight chunks" (64 input channels of the mix each) that go through the same
+    // LDS staging as the convolution weights
+    const float4 *gsrc = (const float4 *)p.gamma;
+    auto load_w = [&](const float4 *chunk_src, float4 (&dst)[STAGE]) {
+        const float4 *s = chunk_src + tid;
 #pragma unroll
         for (int r = 0; r < STAGE; ++r) dst[r] = s[r * NT];
     };
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
 
     float4 bcur[4], bnext[4], wreg[STAGE];
-    load_w(0, wreg);
+    load_w(wsrc, wreg);
     load_b(0, bcur);
     store_w(0, wreg);
     __syncthreads();
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
     const int nch = ph.nchunks;
     for (int ch = 0; ch < nch; ++ch) {
         const int nxt = (ch + 1 < nch) ? ch + 1 : ch;     // unconditional prefetch keeps everything in registers
-        load_w(nxt, wreg);
+        load_w((ch + 1 < nch || EPI != EPI_GDN) ? wsrc + (int64_t)nxt * CHUNK_F4 : gsrc, wreg);   // after the last chunk: gamma
         load_b(nxt, bnext);
         const float4 *wl = lds + (ch & 1) * CHUNK_F4 + h * COUT + j;
 #pragma unroll
@@ -149,57 +152,56 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
             }
         if constexpr (EPI == EPI_GDN) {
             const bool inverse = p.act == MPC_ACT_IGDN;
-            // outputs go through the wave-private transposing store (2 bytes per element: 192 channels per round)
-            TransStore ts;
-            ts.init((char *)lds, wave, lane, j, h,
-                    pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
-            // the B operand of the channel mix (scaled squares in fp16), built once for all output tiles
-            half8 q[NF][2];
+            // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF/2 more iterations of the K loop.  The B operand is built from
+            // the lane's own accumulators: registers 8s..8s+7 of tile f, squared, are the 8 k-values of one k-step, in the
+            // order c = 32f + 16s + 8(jj>>2) + 4h + (jj&3); k-step ks of gamma chunk kc is (f, s) = (2kc + (ks>>1), ks&1).
+            // y^2 is scaled by 2^-8 and saturated before the conversion to fp16; the scale is undone on the fp32 sum.
+            f32x16 nrm[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+#pragma unroll
+            for (int kc = 0; kc < NF / 2; ++kc) {
+                load_w(gsrc + (int64_t)(kc + 1 < NF / 2 ? kc + 1 : kc) * CHUNK_F4, wreg);
+                const float4 *wl = lds + ((nch + kc) & 1) * CHUNK_F4 + h * COUT + j;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    half8 bv;
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
-                        float y = acc[f][8 * s + jj];
-                        q[f][s][jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                        float y = acc[2 * kc + (ks >> 1)][8 * (ks & 1) + jj];
+                        bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
                     }
-#pragma unroll 1
-            for (int fo = 0; fo < NF; ++fo) {
-                f32x16 nrm;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
-                // permuted gamma row of output channel 32fo + j: slots [(f*2 + s)*2 + h] of 8 halfs
-                const float4 *grow = (const float4 *)((const _Float16 *)p.gamma + (int64_t)(32 * fo + j) * COUT) + h;
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(grow[(f * 2 + s) * 2]), q[f][s], nrm, 0, 0, 0);
-                f32x16 yv;
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-                    if (f == fo) yv = acc[f];
-                {
-                    const int rbase = (fo % 6) * 64;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        int c0 = 32 * fo + 8 * g + 4 * h;
-                        float4 be = *(const float4 *)(p.beta + c0);
-                        const float bev[4] = {be.x, be.y, be.z, be.w};
-                        half4 o;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            float n = sqrtf(nrm[4 * g + t] * SQ_UNSCALE + bev[t]);
-                            float y = yv[4 * g + t];
-                            o[t] = sat_half(inverse ? y * n : y / n);
-                        }
-                        *(half4 *)ts.at(j, rbase + (8 * g + 4 * h) * 2) = o;
-                    }
-                    if (fo % 6 == 5 || fo == NF - 1)
-                        ts.flush((char *)p.out, (long long)COUT * 2, (fo / 6) * TS_ROW_BYTES, (fo % 6 + 1) * 64);
+                    for (int fo = 0; fo < NF; ++fo)
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[(ks * 2) * COUT + fo * 32]), bv, nrm[fo], 0, 0, 0);
                 }
+                store_w((nch + kc + 1) & 1, wreg);
+                __syncthreads();
             }
+            // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
+            // all 192 channels in one round); v_rsq_f32 is far more accurate than the fp16 output
+            TransStore ts;
+            ts.init((char *)lds, wave, lane, j, h,
+                    pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 be = *(const float4 *)(p.beta + 32 * f + 8 * g + 4 * h);
+                    const float bev[4] = {be.x, be.y, be.z, be.w};
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float a = nrm[f][4 * g + t] * SQ_UNSCALE + bev[t];
+                        float rs = __builtin_amdgcn_rsqf(a);
+                        float y = acc[f][4 * g + t];
+                        o[t] = sat_half(inverse ? y * (a * rs) : y * rs);
+                    }
+                    *(half4 *)ts.at(j, f * 64 + (8 * g + 4 * h) * 2) = o;
+                }
+            ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
         } else {
             if (!pvalid) return;
             _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;

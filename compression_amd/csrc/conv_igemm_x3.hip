@@ -120,8 +120,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
         }
     };
     const float4 *wsrc = (const float4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group + ph.w_off);
-    auto load_w = [&](int chunk, float4 (&dst)[STAGE]) {
-        const float4 *s = wsrc + (int64_t)chunk * CHUNK_F4 + tid;
+    // GDN channel mix on the fp16 pipe: gamma is packed as NF more "weight chunks" (one per 32 input channels
+    // of the mix) that go through the same LDS staging as the convolution weights
+    const bool gdn_mix16 = (EPI == EPI_GDN) && p.y2_scale > 0.0f;
+    const float4 *gsrc = (const float4 *)p.gamma_x3;
+    auto load_w = [&](const float4 *chunk_src, float4 (&dst)[STAGE]) {
+        const float4 *s = chunk_src + tid;
 #pragma unroll
         for (int r = 0; r < STAGE; ++r) dst[r] = s[r * NT];
     };
@@ -138,15 +142,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
 
     float4 bcur[4], bnext[4], wreg[STAGE];
-    load_w(0, wreg);
+    load_w(wsrc, wreg);
     load_b(0, bcur);
     store_w(0, wreg);
     __syncthreads();
 
     const int nch = ph.nchunks;
     for (int ch = 0; ch < nch; ++ch) {
+        // unconditional prefetch (keeps everything in registers); after the last chunk: the first gamma chunk
         const int nxt = (ch + 1 < nch) ? ch + 1 : ch;
-        load_w(nxt, wreg);
+        load_w((ch + 1 < nch || !gdn_mix16) ? wsrc + (int64_t)nxt * CHUNK_F4 : gsrc, wreg);
         load_b(nxt, bnext);
         // slot index ((ks*2 + h)*2 + part)*COUT + cout
         const float4 *wl = lds + (ch & 1) * CHUNK_F4 + (h * 2) * COUT + j;
@@ -186,55 +191,105 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
 
     if constexpr (EPI == EPI_GDN) {
         const bool inverse = p.act == MPC_ACT_IGDN;
+        const long long pixel_bytes = (long long)COUT * 4;
+        if (gdn_mix16) {
+            // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF more iterations of the K loop: chunk kc holds gamma[:, 32kc..32kc+31]
+            // (hi/lo, scaled) in the weight-chunk layout; the B operand is built from the lane's own accumulators, whose
+            // registers 8s..8s+7 of tile kc are the 8 k-values of k-step s:  c = 32kc + 16s + 8(jj>>2) + 4h + (jj&3).
+            f32x16 nrm[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+#pragma unroll
+            for (int kc = 0; kc < NF; ++kc) {
+                load_w(gsrc + (int64_t)(kc + 1 < NF ? kc + 1 : kc) * CHUNK_F4, wreg);
+                const float4 *wl = lds + ((nch + kc) & 1) * CHUNK_F4 + (h * 2) * COUT + j;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    half8 bh, bl;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        float y = acc[kc][8 * s + jj];
+                        float q = fminf(y * y * p.y2_scale, 65504.0f);
+                        _Float16 hh = (_Float16)q;
+                        bh[jj] = hh;
+                        bl[jj] = (_Float16)(q - (float)hh);
+                    }
+#pragma unroll
+                    for (int fo = 0; fo < NF; ++fo) {
+                        const half8 ah = as_half8(wl[(s * 4) * COUT + fo * 32]);
+                        const half8 al = as_half8(wl[(s * 4 + 1) * COUT + fo * 32]);
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm[fo], 0, 0, 0);
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
+                    }
+                }
+                store_w((nch + kc + 1) & 1, wreg);
+                __syncthreads();
+            }
+            // y * (beta + norm)^(-1/2) (or ^(+1/2)); v_rsq_f32 is good to 1 ulp
+            TransStore ts;
+            ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int rbase = (f % 3) * 128;              // byte offset of this tile inside the round's row
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 be = *(const float4 *)(p.beta + 32 * f + 8 * g + 4 * h);
+                    const float bev[4] = {be.x, be.y, be.z, be.w};
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float a = nrm[f][4 * g + t] * p.gdn_unscale + bev[t];
+                        float rs = __builtin_amdgcn_rsqf(a);
+                        float y = acc[f][4 * g + t];
+                        o[t] = inverse ? y * (a * rs) : y * rs;
+                    }
+                    if (out_split) {
+                        // block g of the tile: [hi x8 | lo x8]; this lane half owns elements 4h..4h+3 of each
+                        half4 hi4, lo4;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
+                            _Float16 hh = (_Float16)sv;
+                            hi4[t] = hh;
+                            lo4[t] = (_Float16)(sv - (float)hh);
+                        }
+                        *(half4 *)ts.at(j, rbase + g * 32 + 8 * h) = hi4;
+                        *(half4 *)ts.at(j, rbase + g * 32 + 16 + 8 * h) = lo4;
+                    } else {
+                        *(float4 *)ts.at(j, rbase + (8 * g + 4 * h) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+                // 96 channels (384 bytes per pixel) per round
+                if (f % 3 == 2) ts.template flush<24>((char *)p.out, pixel_bytes, (f / 3) * TS_ROW_BYTES);
+                else if (f == NF - 1) ts.template flush<(NF % 3) * 8>((char *)p.out, pixel_bytes, (f / 3) * TS_ROW_BYTES);
+            }
+            return;
+        }
+        // exact f32 channel mix (layers created without an input bound), one output tile at a time
         // outputs go through the wave-private transposing store (4 bytes per element: 96 channels per round)
         TransStore ts;
         ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
-        const long long pixel_bytes = (long long)COUT * 4;
 #pragma unroll 1
         for (int fo = 0; fo < NF; ++fo) {
             f32x16 nrm;
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
-            if (p.y2_scale > 0.0f) {
-                // split-precision channel mix: gamma = g_hi + g_lo (scaled), y^2 = q_hi + q_lo (scaled), three
-                // fp16 MFMAs; k order of the accumulator registers: c = 32f + 16s + 8(jj>>2) + 4h + (jj&3)
-                const float4 *grow = (const float4 *)((const _Float16 *)p.gamma_x3 + (int64_t)(32 * fo + j) * COUT * 2) + h * 2;
+            const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
 #pragma unroll
-                for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f) {
+                float4 ga[4];
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const half8 ah = as_half8(grow[(f * 2 + s) * 4]);
-                        const half8 al = as_half8(grow[(f * 2 + s) * 4 + 1]);
-                        half8 bh, bl;
+                for (int g = 0; g < 4; ++g) ga[g] = *(const float4 *)(grow + 32 * f + 8 * g);
 #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) {
-                            float y = acc[f][8 * s + jj];
-                            float q = fminf(y * y * p.y2_scale, 65504.0f);
-                            _Float16 hh = (_Float16)q;
-                            bh[jj] = hh;
-                            bl[jj] = (_Float16)(q - (float)hh);
-                        }
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm, 0, 0, 0);
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm, 0, 0, 0);
-                        nrm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm, 0, 0, 0);
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const float av[4] = {ga[g].x, ga[g].y, ga[g].z, ga[g].w};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nrm[r] *= p.gdn_unscale;
-            } else {
-                const float *grow = (const float *)p.gamma + (int64_t)(32 * fo + j) * COUT + 4 * h;
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    float4 ga[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) ga[g] = *(const float4 *)(grow + 32 * f + 8 * g);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float av[4] = {ga[g].x, ga[g].y, ga[g].z, ga[g].w};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            float y = acc[f][4 * g + t];
-                            nrm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], y * y, nrm, 0, 0, 0);
-                        }
+                    for (int t = 0; t < 4; ++t) {
+                        float y = acc[f][4 * g + t];
+                        nrm = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], y * y, nrm, 0, 0, 0);
                     }
                 }
             }
@@ -272,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
                         *(float4 *)ts.at(j, rbase + (8 * g + 4 * h) * 4) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
-                if (fo % 3 == 2 || fo == NF - 1) ts.flush((char *)p.out, pixel_bytes, (fo / 3) * TS_ROW_BYTES, (fo % 3 + 1) * 128);
+                if (fo % 3 == 2 || fo == NF - 1) ts.flush((char *)p.out, pixel_bytes, (fo / 3) * TS_ROW_BYTES, (fo % 3 + 1) * 8);
             }
         }
     } else {
