@@ -130,6 +130,7 @@ struct mpc_conv {
     bool cin4, stacked, f16, x3;
     float w_scale = 1.0f;  // f16x3: power-of-two weight scale
     void *gamma_x3 = nullptr;
+    void *wpk_rgb16 = nullptr;   // fp16 last layer: A image of the 16-row kernel (conv_rgb_out_f16.hip)
     float gamma_scale = 0.0f, y2_scale = 0.0f;
     int nphase;
     int sy, sx, my, mx;
@@ -142,5 +143,10 @@ struct mpc_conv {
 
 // f16 path (conv_igemm_f16.hip)
 int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
+// fp16 last layer, cout <= 4 (conv_rgb_out_f16.hip)
+bool mpc_conv_rgb16_supported(int cin, int cout);
+size_t mpc_conv_rgb16_image_bytes(int cin);
+hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *image, hipStream_t stream);
+int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // split-fp16 path (conv_igemm_x3.hip)
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);

@@ -603,6 +603,10 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         pack_weights_kernel<<<dim3((unsigned)mpc_cdiv(w_total, 256)), dim3(256), 0, ctx->stream>>>(pd, weight, c->wpk, w_total);
     }
     if ((e = hipGetLastError()) != hipSuccess) return fail("pack_weights launch");
+    if (f16 && stacked && mpc_conv_rgb16_supported(d.cin, d.cout)) {
+        if ((e = hipMalloc(&c->wpk_rgb16, mpc_conv_rgb16_image_bytes(d.cin))) != hipSuccess) return fail("hipMalloc(rgb16 weights)");
+        if ((e = mpc_conv_rgb16_pack(weight, d.cin, d.cout, c->wpk_rgb16, ctx->stream)) != hipSuccess) return fail("pack_rgb16 launch");
+    }
     if (gdn) {
         const float pedestal = 0x1p-36f;
         const float beta_bound = (float)sqrt(1e-6 + 0x1p-36);
@@ -658,6 +662,7 @@ int mpc_conv_destroy(mpc_conv *c) {
     if (!c) return MPC_OK;
     (void)hipFree(c->wpk); (void)hipFree(c->bias); (void)hipFree(c->beta); (void)hipFree(c->gamma); (void)hipFree(c->taps);
     (void)hipFree(c->gamma_x3);
+    (void)hipFree(c->wpk_rgb16);
     delete c;
     return MPC_OK;
 }

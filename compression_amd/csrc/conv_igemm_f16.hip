@@ -252,7 +252,7 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase) {
 
 int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
-    if (c->stacked) return launch<1, EPI_STACKED>(ctx, p, c->nphase);
+    if (c->stacked) return c->wpk_rgb16 ? mpc_conv_launch_rgb16(ctx, p, c) : launch<1, EPI_STACKED>(ctx, p, c->nphase);
     if (gdn) {
         if (c->nf == 4) return launch<4, EPI_GDN>(ctx, p, c->nphase);
         if (c->nf == 6) return launch<6, EPI_GDN>(ctx, p, c->nphase);

@@ -1,0 +1,169 @@
+// Last layer of the synthesis transform on the fp16 matrix pipe: ConvTranspose2d(cin -> cout <= 4, k5, s2,
+// p2, output_padding 1) writing the fp32 NCHW image (Balle2018PT_compressor.py:105-127, the deconv to 3
+// channels; testolina_compressor.py:91-100).
+//
+// All four output parities of a base pixel are rows of ONE small GEMM over the 3x3 input neighbourhood:
+//   D[row][pixel] = sum_{tap, c} A[row][tap, c] * in[pixel + tap][c],   row = (co*2 + ypar)*2 + xpar  (4*cout <= 16 rows)
+// which is the shape of v_mfma_f32_16x16x32_f16: 16 rows x 16 pixels x 32 input channels per instruction
+// (12 of 16 rows are real for cout = 3, against 12 of 32 on the 32x32 tile).  The whole A operand
+// (9 taps x cin x 16 rows, 2 KB per 64 channels and tap) stays in LDS for the life of a persistent
+// workgroup, so the K loop has no barrier; a wave walks over 64-pixel tiles (four 16-pixel MFMA columns
+// sharing every A fragment).  The B operand is read straight from the fp16 NHWC activations: lane
+// (pixel n, k-group kg) loads 16 bytes, so the four lanes of a pixel cover 64 contiguous bytes per load.
+// The x-parity pair of a row pair lands in consecutive accumulator registers of one lane: the output is
+// written as float2, 128 contiguous bytes per 16 lanes.
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int RGB16_WAVES = 8;
+constexpr int RGB16_TILE = 64;            // pixels per wave tile
+
+__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
+
+// A image: [tap 9][chunk cin/64][kstep 2][lane 64][8 halfs]; lane = kg*16 + row holds channels
+// chunk*64 + kstep*32 + kg*8 + jj of its row.  Row (co, ypar, xpar) uses weight tap ky = ypar + 2 - 2dy,
+// kx = xpar + 2 - 2dx (oy = 2*iy - 2 + ky with oy = 2*by + ypar, iy = by + dy); taps outside the 5x5 kernel are 0.
+__global__ void pack_rgb16_kernel(const float *__restrict__ w, int cin, int cout, _Float16 *__restrict__ out, int total) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cb = cin / 64;
+    int jj = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, rest = i >> 10;
+    int chunk = rest % cb, tap = rest / cb;
+    int row = lane & 15, kg = lane >> 4;
+    int c = chunk * 64 + ks * 32 + kg * 8 + jj;
+    int xpar = row & 1, ypar = (row >> 1) & 1, co = row >> 2;
+    int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    int ky = ypar + 2 - 2 * dy, kx = xpar + 2 - 2 * dx;
+    float v = 0.0f;
+    if (co < cout && ky >= 0 && ky < 5 && kx >= 0 && kx < 5) v = w[(((int64_t)c * cout + co) * 5 + ky) * 5 + kx];
+    out[i] = (_Float16)v;
+}
+
+__global__ __launch_bounds__(64 * RGB16_WAVES, 2) void deconv_rgb16_kernel(const Params p, const float4 *__restrict__ wimg, int nsteps,
+                                                                             int64_t ntiles) {
+    extern __shared__ float4 lds[];                        // nsteps * 128 float4
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nsteps * 128; i += 64 * RGB16_WAVES) lds[i] = wimg[i];
+    __syncthreads();
+
+    const int lane = tid & 63, n = lane & 15, kg = lane >> 4, wave = tid >> 6;
+    const int cb = p.cin_blocks;                           // cin / 64
+    const _Float16 *in = (const _Float16 *)p.in;
+    float *out = (float *)p.out;
+    const bool clamp01 = (p.flags & MPC_OUT_CLAMP01) != 0;
+    const int64_t hw = (int64_t)p.Hb * p.Wb;
+
+    // XCD c (workgroups c, c+8, ...) walks the c-th contiguous eighth of the tiles, a wave at a time
+    const int64_t per_xcd = (ntiles + NUM_XCD - 1) / NUM_XCD;
+    const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
+    const int64_t t1 = (t0 + per_xcd < ntiles) ? t0 + per_xcd : ntiles;
+    const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * RGB16_WAVES;
+    for (int64_t t = t0 + (int64_t)(blockIdx.x / NUM_XCD) * RGB16_WAVES + wave; t < t1; t += stride) {
+        bool valid[4];
+        int pb[4], py[4], px[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t pix = t * RGB16_TILE + u * 16 + n;
+            valid[u] = pix < p.P;
+            pb[u] = py[u] = px[u] = 0;
+            if (valid[u]) {
+                pb[u] = (int)(pix / hw);
+                int rem = (int)(pix - (int64_t)pb[u] * hw);
+                py[u] = rem / p.Wb;
+                px[u] = rem - py[u] * p.Wb;
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        auto load_b = [&](int step, float4 (&dst)[2][4]) {
+            int tap = step / cb, chunk = step - tap * cb;
+            int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int iy = py[u] + dy, ix = px[u] + dx;
+                bool ok = valid[u] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+                const _Float16 *src = in + (((int64_t)pb[u] * p.Hi + iy) * p.Wi + ix) * p.Cs + chunk * 64 + kg * 8;
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (ok) {
+                    v0 = *(const float4 *)src;
+                    v1 = *(const float4 *)(src + 32);
+                }
+                dst[0][u] = v0;
+                dst[1][u] = v1;
+            }
+        };
+
+        float4 bcur[2][4], bnext[2][4];
+        load_b(0, bcur);
+        for (int s = 0; s < nsteps; ++s) {
+            load_b(s + 1 < nsteps ? s + 1 : s, bnext);     // unconditional prefetch
+            const half8 a0 = as_half8(lds[(s * 2) * 64 + lane]), a1 = as_half8(lds[(s * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, as_half8(bcur[0][u]), acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, as_half8(bcur[1][u]), acc[u], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bcur[k][u] = bnext[k][u];
+        }
+
+        // lane (n, kg) holds rows 4kg..4kg+3 of pixel n: (co, ypar) = (kg, 0) in registers 0,1 and (kg, 1) in 2,3
+        if (kg < p.cout) {
+            const float bias = p.bias[kg];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!valid[u]) continue;
+#pragma unroll
+                for (int yp = 0; yp < 2; ++yp) {
+                    float v0 = acc[u][2 * yp] + bias, v1 = acc[u][2 * yp + 1] + bias;
+                    if (clamp01) {
+                        v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
+                        v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
+                    }
+                    float *o = out + (((int64_t)pb[u] * p.cout + kg) * p.Ho + 2 * py[u] + yp) * p.Wo + 2 * px[u];
+                    *(float2 *)o = make_float2(v0, v1);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// bytes of the packed A image
+size_t mpc_conv_rgb16_image_bytes(int cin) { return (size_t)9 * (cin / 64) * 2 * 64 * 16; }
+
+bool mpc_conv_rgb16_supported(int cin, int cout) {
+    return cout >= 1 && cout <= 4 && cin % 64 == 0 && mpc_conv_rgb16_image_bytes(cin) <= 72 * 1024;
+}
+
+hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *image, hipStream_t stream) {
+    const int total = (int)(mpc_conv_rgb16_image_bytes(cin) / sizeof(_Float16));
+    pack_rgb16_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, stream>>>(weight, cin, cout, (_Float16 *)image, total);
+    return hipGetLastError();
+}
+
+int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    const int nsteps = 9 * (c->desc.cin / 64);
+    const size_t lds = mpc_conv_rgb16_image_bytes(c->desc.cin);
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)deconv_rgb16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int64_t ntiles = mpc_cdiv(p.P, RGB16_TILE);
+    // persistent workgroups: two per CU while there is work for them, a multiple of the XCD count
+    int64_t blocks = mpc_cdiv(ntiles, RGB16_WAVES);
+    if (blocks > 2 * NUM_CU) blocks = 2 * NUM_CU;
+    blocks = xcd_grid(blocks);
+    deconv_rgb16_kernel<<<dim3((unsigned)blocks), dim3(64 * RGB16_WAVES), lds, ctx->stream>>>(p, (const float4 *)c->wpk_rgb16, nsteps, ntiles);
+    MPC_CHECK_LAUNCH(ctx, "deconv_rgb16");
+    return MPC_OK;
+}

@@ -343,6 +343,8 @@ class ConvLayer:
             ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
         self._launches = (tiles // nf) * (4 if (kind == _lib.MPC_DECONV and stride == 2 and not self.small_cout) else 1)
         self.kernel_name = self._name_fmt % 4 if (x3 or f16) else self._name_fmt
+        # the fp16 last layer (cout <= 4) has a kernel of its own
+        self._rgb16 = f16 and self.small_cout and cout <= 4 and cin % 64 == 0 and cin <= 256
         ctx = context_for(w.device)
         h = c_void_p()
         ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
@@ -382,7 +384,7 @@ class ConvLayer:
             # mirrors the library's choice of waves per workgroup (for the kernel name in profiles)
             base = B * (H * W if self.kind == _lib.MPC_DECONV else Ho * Wo)
             wide = (wide_block or -(-base // 256) * self._launches >= 512) and not self.small_cout
-            self.kernel_name = self._name_fmt % (8 if wide else 4)
+            self.kernel_name = "deconv_rgb16_kernel" if self._rgb16 else self._name_fmt % (8 if wide else 4)
         if out_split:
             shape, odt = (B, Ho, Wo, self.cout // 8, 16), torch.float16
         else:
