@@ -1,6 +1,21 @@
 // Context management and layout / elementwise helpers of libmpc.
 #include "mpc_internal.h"
 
+void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return ctx->scratch;
+    (void)hipFree(ctx->scratch);                // synchronises with work still using the old buffer
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    if (e != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "scratch allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        ctx->scratch = nullptr;
+        return nullptr;
+    }
+    ctx->scratch_bytes = bytes;
+    return ctx->scratch;
+}
+
 extern "C" {
 
 const char *mpc_version(void) { return "libmpc 0.1 gfx950 (hand-written HIP, f32 MFMA transforms, MRS1 rANS)"; }
@@ -20,6 +35,7 @@ int mpc_create(int device_id, void *stream, mpc_ctx **out) {
 }
 
 int mpc_destroy(mpc_ctx *ctx) {
+    if (ctx) (void)hipFree(ctx->scratch);
     delete ctx;
     return MPC_OK;
 }

@@ -11,7 +11,13 @@ struct mpc_ctx {
     int device;
     hipStream_t stream;
     char err[512];
+    void *scratch = nullptr;      // library-owned device scratch, grown on demand (mpc_ctx_scratch)
+    size_t scratch_bytes = 0;
 };
+
+// Device scratch of at least `bytes` owned by the context (contents undefined; valid until the next call
+// that asks for more).  Returns nullptr and sets the context's error text on failure.
+void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes);
 
 #define MPC_FAIL(ctx, code, ...)                                   \
     do {                                                           \

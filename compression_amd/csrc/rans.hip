@@ -285,169 +285,252 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fast decoder for 256-symbol rows (L = 257, the standard table): the row of every symbol is staged
-// global -> registers -> LDS two symbols ahead of its use, and the symbol is found with a two-level
-// search in LDS (16 segment heads, then the 16 entries of the segment), one 16-lane ballot per level.
-// Per symbol the coder state waits on two LDS round trips instead of global-memory round trips.
+// Fast decoder for 256-symbol rows (L = 257, the standard table).
+//
+// The serial chain of a stream is: state -> symbol search in the symbol's CDF row -> new state.  The
+// row of every symbol is known in advance (prior index of the location, channel), so rows are
+// streamed into an LDS ring by LDS-DMA loads (global -> LDS, no registers) DEPTH symbols ahead of
+// their use and retired with counted waits: the coder state only ever waits on LDS.  LDS-DMA writes
+// lane-linear 16-byte pieces, so a wave (four 16-lane groups = four streams) stages the rows of its four
+// streams with two instructions per symbol: piece t of half h of group g's row lands at
+// ring[slot][h][g][t].  The rows come from a copy of the table with a 16-byte aligned row pitch.
+// The symbol is found with a two-level search (16 segment heads, then the 16 entries of the segment),
+// one 16-lane ballot per level.
 // ---------------------------------------------------------------------------------------------
-constexpr int RING = 4;                    // LDS row slots per group (rows i .. i+1 are live, 4 for slack)
+constexpr int RING = 8;                    // LDS row slots per workgroup (power of two, >= AHEAD + 2)
+constexpr int INFLIGHT = 3;                // rows whose DMA may still be in flight behind the newest issued one
+constexpr int AHEAD = INFLIGHT + 1;        // barriers the loader runs ahead of the decoder
+constexpr int DMA_PITCH = 264;             // row pitch (entries) of the aligned table copy: 528 bytes
+constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
 
-struct RowRegs {
-    uint4 a, b;                            // 16 u16 entries: 16t .. 16t+15 of the row
-};
+// s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
+#define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
-__device__ __forceinline__ RowRegs load_row(const uint16_t *row, int t) {
-    Row16 r = *(const Row16 *)(row + 16 * t);
-    return __builtin_bit_cast(RowRegs, r);
+// loader tail: one barrier per remaining row, waiting until at most K rows are in flight before each
+template <int K>
+__device__ __forceinline__ void drain_rows() {
+    MPC_WAIT_VMCNT(2 * (K > 0 ? K : 0));
+    __builtin_amdgcn_s_barrier();
+    if constexpr (K > -1) drain_rows<K - 1>();
 }
 
-__global__ __launch_bounds__(256) void decode_streams_lds_kernel(Geometry g, const uint16_t *__restrict__ table,
+__global__ void align_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, int L, uint16_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * DMA_PITCH) return;
+    int64_t r = i / DMA_PITCH;
+    int c = (int)(i - r * DMA_PITCH);
+    out[i] = c < L ? table[r * L + c] : (uint16_t)0;
+}
+
+// Workgroup = two waves working on the same four streams: wave 1 streams the CDF rows into an LDS ring (the
+// loader), wave 0 runs the coder states, one 16-lane group per stream (the decoder).  Within a wave the
+// hardware keeps DS instructions and LDS-DMA loads in order (a ds_read issued after a DMA waits for it to
+// land), so a wave that both loads and searches serialises on every row; the loader therefore executes no DS
+// instruction in its loop, and the two waves meet at one raw s_barrier per symbol:
+//   loader, iteration i : issue row i (slot i % RING); wait until rows <= i - INFLIGHT have landed; barrier #i
+//   decoder, step n     : barrier #(n + AHEAD); search row n, read the segment heads of row n + 1
+// Barrier #(n + AHEAD) follows the loader's wait for row n + 1.  The loader overwrites the slot of row
+// i - RING only after barrier #(i - 1), which the decoder passed before step i - 1 - AHEAD, when every read up
+// to row i - AHEAD - 1 >= i - RING + 1 had been issued and consumed.  Both waves execute nmax + AHEAD barriers.
+//
+// The decoder's serial chain per symbol is: ballot over the 16 segment heads (in registers, read a step
+// ahead) -> read the segment's 16 entries -> ballot -> read (start, end) -> new state.  The next
+// renormalisation word is read from an LDS copy of the stream's words a step ahead as well.
+__global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, const uint16_t *__restrict__ table,
                                                                   const int32_t *__restrict__ idx,
                                                                   const uint8_t *__restrict__ in, size_t in_stride,
                                                                   const uint64_t *__restrict__ nbytes,
                                                                   int16_t *__restrict__ sym_out,
                                                                   int32_t *__restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint16_t rows_sh[GROUPS_PER_BLOCK][RING][256];
-    __shared__ uint16_t heads_sh[GROUPS_PER_BLOCK][RING][16];
-    const int t = threadIdx.x & (GROUP - 1);
-    const int gi = threadIdx.x / GROUP;                    // group within the block
-    const int gshift = (threadIdx.x & 63) & ~(GROUP - 1);  // bit offset of this group in a wave ballot
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + gi;
+    static_assert(RING >= AHEAD + 2 && (RING & (RING - 1)) == 0, "ring too small for the DMA lead");
+    __shared__ __attribute__((aligned(16))) uint16_t ring[RING][4][256];         // [slot][group][entry]
+    __shared__ __attribute__((aligned(16))) uint16_t wring[4][WRING];            // renormalisation words per group
+    __shared__ uint32_t info[4][3];                                              // per group: first symbol, end symbol, image
+    __shared__ uint32_t nmax_sh;
+    const int lane = threadIdx.x & 63;
+    const bool loader = (threadIdx.x >> 6) == 1;
+    const int t = lane & (GROUP - 1);
+    const int gw = lane / GROUP;                           // group within the wave
+    const int gshift = lane & ~(GROUP - 1);                // bit offset of this group in a wave ballot
     const int64_t G = (int64_t)g.n_images * g.n_streams;
-    if (gid >= G) return;
-    const int img = (int)(gid / g.n_streams);
-    const uint32_t stream = (uint32_t)(gid % g.n_streams);
-    const uint8_t *src = in + (size_t)img * in_stride;
-    const uint64_t nb = nbytes[img];
-    const uint32_t hdr = 16 + 2 * (uint32_t)g.n_streams;
+    const uint32_t M = (uint32_t)g.M;
+
+    // ---- stream set-up (decoder wave), handed to the loader through LDS ----
     int err = 0;
-    if (nb < hdr) err = -20;
-    uint32_t my_len = 0, off = hdr;
-    if (!err) {
-        const uint32_t *h4 = (const uint32_t *)src;
-        if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
+    uint32_t my_len = 0, b = 0, e = 0;
+    int img = 0;
+    const uint16_t *words = nullptr;
+    bool live = false;
+    if (!loader) {
+        const int64_t gid = (int64_t)blockIdx.x * 4 + gw;
+        live = gid < G;                                    // dead groups idle through the loop
+        img = live ? (int)(gid / g.n_streams) : 0;
+        const uint32_t stream = live ? (uint32_t)(gid % g.n_streams) : 0;
+        const uint8_t *src = in + (size_t)img * in_stride;
+        const uint64_t nb = nbytes[img];
+        const uint32_t hdr = 16 + 2 * (uint32_t)g.n_streams;
+        if (nb < hdr) err = -20;
+        uint32_t off = hdr;
+        if (!err) {
+            const uint32_t *h4 = (const uint32_t *)src;
+            if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
+        }
+        if (!err) {
+            const uint16_t *lens = (const uint16_t *)(src + 16);
+            uint32_t acc = 0;
+            for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
+            off += 2 * group_sum(acc);
+            my_len = lens[stream];
+            if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
+        }
+        words = (const uint16_t *)(src + off);
+        if (live && !err) {
+            b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
+            e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
+        }
+        if (b < e) {                                       // validate the prior indices of this stream once
+            const int32_t *img_idx = idx + (int64_t)img * g.n_loc;
+            for (uint32_t l = b / M + t; l < (e + M - 1) / M; l += GROUP) {
+                int k = img_idx[l];
+                if (k < 0 || k >= g.K) err = -23;
+            }
+            if (__ballot(err != 0) >> gshift & 0xffffu) err = -23;
+            if (err) e = b;
+        }
+        uint32_t nm = e - b;
+#pragma unroll
+        for (int o = 32; o >= GROUP; o >>= 1) nm = max(nm, (uint32_t)__shfl_xor((int)nm, o, 64));
+        if (t == 0) { info[gw][0] = b; info[gw][1] = e; info[gw][2] = (uint32_t)img; }
+        if (lane == 0) nmax_sh = nm;
     }
-    if (!err) {
-        const uint16_t *lens = (const uint16_t *)(src + 16);
-        uint32_t acc = 0;
-        for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
-        off += 2 * group_sum(acc);
-        my_len = lens[stream];
-        if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
-    }
-    if (err) {
-        if (t == 0) atomicMin(&status[img], err);
+    __syncthreads();
+    const uint32_t nmax = nmax_sh;                         // trip count of the workgroup
+    if (nmax == 0) {
+        if (!loader && err && live && t == 0) atomicMin(&status[img], err);
         return;
     }
-    const uint16_t *words = (const uint16_t *)(src + off);
-    uint32_t x = (uint32_t)words[0] | ((uint32_t)words[1] << 16);
-    // Renormalisation words are kept in a 32-word register window spread over the group's 16 lanes (lane t
-    // holds words wbase+t and wbase+16+t) and read with a lane shuffle, so the coder state never waits on a
-    // global load; the window is refilled 16 words ahead of its use.
-    uint32_t wpos = 2, wbase = 2;                          // next word to consume; first word of the window
-    auto fetch = [&](uint32_t k) -> uint32_t { return k < my_len ? (uint32_t)words[k] : 0u; };
-    uint32_t win0 = fetch(wbase + t), win1 = fetch(wbase + 16 + t);
 
-    uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
-    uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
-    const int32_t *img_idx = idx + (int64_t)img * g.n_loc;
+    if (loader) {
+        // Each half-wave copies whole rows: lanes 32h..32h+31 bring the 32 16-byte pieces of the row of group h
+        // (first instruction) and of group 2 + h (second instruction); one instruction fills two groups' rows
+        // ([slot][g][256] is lane-linear for it).  Row cursors walk the symbols b, b+1, ... of their stream and
+        // stay on the last symbol at the end (table is the aligned copy: row (k, c) at (k*M + c) * DMA_PITCH).
+        const int hw = lane >> 5, piece = lane & 31;
+        uint32_t ci[2], cc[2], cloc[2], ce[2];
+        const int32_t *cidx[2];
+        const uint16_t *crow[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gq = 2 * q + hw;
+            const uint32_t qb = info[gq][0];
+            ce[q] = info[gq][1];
+            cidx[q] = idx + (int64_t)info[gq][2] * g.n_loc;
+            ci[q] = qb; cc[q] = qb % M; cloc[q] = qb / M;
+            crow[q] = table;
+            if (qb < ce[q]) crow[q] = table + ((int64_t)cidx[q][cloc[q]] * M + cc[q]) * DMA_PITCH;
+        }
+        __builtin_amdgcn_s_waitcnt(0);                     // the set-up's LDS reads are done before the first DMA
+        for (uint32_t i = 0; i < nmax; ++i) {
+            const int slot = (int)(i & (RING - 1));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[0] + 8 * piece),
+                                             (__attribute__((address_space(3))) void *)&ring[slot][0][0], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[1] + 8 * piece),
+                                             (__attribute__((address_space(3))) void *)&ring[slot][2][0], 16, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (ci[q] + 1 < ce[q]) {
+                    ++ci[q];
+                    if (++cc[q] == M) {
+                        cc[q] = 0;
+                        ++cloc[q];
+                        crow[q] = table + (int64_t)cidx[q][cloc[q]] * M * DMA_PITCH;   // indices were validated above
+                    } else {
+                        crow[q] += DMA_PITCH;
+                    }
+                }
+            }
+            MPC_WAIT_VMCNT(2 * INFLIGHT);                  // rows land in order: all but the newest INFLIGHT rows are in LDS
+            __builtin_amdgcn_s_barrier();                  // #i
+        }
+        drain_rows<INFLIGHT - 1>();                        // barriers #nmax .. #(nmax + AHEAD - 1), everything landed by the last
+        return;
+    }
+
+    // ---- decoder wave ----
+    if (err && live && t == 0) atomicMin(&status[img], err);
+    const uint32_t len = e - b;
     int16_t *dst = sym_out + (int64_t)img * g.n_symbols;
-    const uint32_t M = (uint32_t)g.M;
-    const int64_t prior_stride = (int64_t)g.M * g.L;
+    // the stream's renormalisation words go through an LDS ring of two 128-word halves: lane t brings 8 words
+    uint16_t *wr = &wring[gw][0];
+    auto fill_half = [&](uint32_t first) {                 // words [first, first + 128) -> ring half (first / 128) & 1
+        const uint32_t k0 = first + 8 * t;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (len && k0 + 8 <= my_len) {
+            v = *(const uint4 *)(words + k0);
+        } else if (len && k0 < my_len) {
+            uint16_t tmp[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tmp[q] = (k0 + q < my_len) ? words[k0 + q] : (uint16_t)0;
+            v = make_uint4(tmp[0] | (uint32_t)tmp[1] << 16, tmp[2] | (uint32_t)tmp[3] << 16, tmp[4] | (uint32_t)tmp[5] << 16,
+                           tmp[6] | (uint32_t)tmp[7] << 16);
+        }
+        *(uint4 *)(wr + ((first + 8 * t) & (WRING - 1))) = v;
+    };
+    fill_half(0);
+    fill_half(128);
+    uint32_t x = len ? ((uint32_t)words[0] | ((uint32_t)words[1] << 16)) : RANS_L;
+    uint32_t wpos = 2, wbase = 0;                          // next word to consume; ring holds words [wbase, wbase + 256)
+    const uint16_t *rbase = &ring[0][gw][0];               // this group's row in slot 0
 
-    // Prefetch cursor: walks the rows of symbols b, b+1, ... (three ahead of the decode position).  The prior
-    // index of a location is read one whole location (M symbols) before its rows are needed, so no row address
-    // ever waits on an index load.
-    const uint32_t loc_last = (e - 1) / M;                 // valid when b < e
-    uint32_t pf_loc = b / M, pf_c = b % M;
-    auto clamp_k = [&](int k) { return (k < 0 || k >= g.K) ? 0 : k; };
-    int pf_k = (b < e) ? clamp_k(img_idx[pf_loc]) : 0;
-    int pf_knext = (b < e && pf_loc < loc_last) ? clamp_k(img_idx[pf_loc + 1]) : pf_k;
-    const uint16_t *pf_row = table + (int64_t)pf_k * prior_stride + (int64_t)pf_c * g.L;
-    uint32_t pf_i = b;
-    // returns the row of the cursor's symbol and advances the cursor (stays on the last symbol at the end)
-    auto next_row = [&]() -> const uint16_t * {
-        const uint16_t *r = pf_row;
-        if (pf_i + 1 < e) {
-            ++pf_i;
-            if (++pf_c == M) {
-                pf_c = 0;
-                ++pf_loc;
-                pf_k = pf_knext;
-                pf_knext = (pf_loc < loc_last) ? clamp_k(img_idx[pf_loc + 1]) : pf_k;
-                pf_row = table + (int64_t)pf_k * prior_stride;
-            } else {
-                pf_row += g.L;
+#pragma unroll
+    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): row 0 has landed
+    asm volatile("" ::: "memory");
+    uint32_t heads = rbase[16 * t];                        // segment heads of row 0
+    uint32_t wnext = wr[wpos & (WRING - 1)];
+    uint32_t xslot = x & 0xffffu;
+    uint32_t mysym = 0;
+    for (uint32_t n = 0; n < nmax; ++n) {
+        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows n and n + 1 have landed
+        asm volatile("" ::: "memory");
+        const uint16_t *row = rbase + (n & (RING - 1)) * (4 * 256);
+        const uint32_t heads_nx = rbase[((n + 1) & (RING - 1)) * (4 * 256) + 16 * t];   // off the chain
+        if (n < len) {
+            unsigned long long m1 = __ballot(heads <= xslot);
+            uint32_t seg_cnt = __popc((uint32_t)(m1 >> gshift) & 0xffffu);
+            uint32_t seg = seg_cnt ? seg_cnt - 1 : 0;      // a row starts at 0, so seg_cnt >= 1 unless the table is corrupt
+            uint32_t ent = row[16 * seg + t];
+            unsigned long long m2 = __ballot(ent <= xslot);
+            uint32_t in_seg = __popc((uint32_t)(m2 >> gshift) & 0xffffu);
+            uint32_t s = 16 * seg + (in_seg ? in_seg - 1 : 0);
+            uint32_t start = row[s];
+            uint32_t endv = row[s + 1];                    // s = 255 reads the next group's first entry (or the word ring): unused
+            uint32_t end = (s == 255u) ? 0x10000u : endv;
+            x = (end - start) * (x >> 16) + xslot - start;
+            const bool ren = x < RANS_L;
+            if (ren) x = (x << 16) | wnext;
+            xslot = x & 0xffffu;
+            // ---- off the chain ----
+            if (seg_cnt == 0 || in_seg == 0) err = -24;
+            if (ren) {
+                if (wpos >= my_len) err = -25;
+                ++wpos;
+                if (wpos - wbase == 128 + 2) {             // a half is behind us (two words of slack): refill it
+                    fill_half(wbase + WRING);
+                    wbase += 128;
+                }
+            }
+            wnext = wr[wpos & (WRING - 1)];
+            // symbols are written 16 at a time, one per lane
+            if (t == (int)(n & 15)) mysym = s;
+            if ((n & 15) == 15 || n + 1 == len) {
+                uint32_t first = n & ~15u;
+                if (first + t <= n) dst[b + first + t] = (int16_t)mysym;
             }
         }
-        return r;
-    };
-    auto stage = [&](int slot, const RowRegs &r) {
-        uint4 *d = (uint4 *)&rows_sh[gi][slot][16 * t];
-        d[0] = r.a;
-        d[1] = r.b;
-        heads_sh[gi][slot][t] = (uint16_t)(r.a.x & 0xffffu);
-    };
-    // decode one symbol from LDS slot `slot`; returns false on a corrupt stream
-    auto decode_one = [&](uint32_t i, int slot) -> bool {
-        const uint32_t xslot = x & 0xffffu;
-        uint32_t head = heads_sh[gi][slot][t];
-        unsigned long long m1 = __ballot(head <= xslot);
-        uint32_t seg_cnt = __popc((uint32_t)(m1 >> gshift) & 0xffffu);
-        if (seg_cnt == 0) { err = -24; return false; }
-        uint32_t seg = seg_cnt - 1;
-        uint32_t ent = rows_sh[gi][slot][16 * seg + t];
-        unsigned long long m2 = __ballot(ent <= xslot);
-        uint32_t s = 16 * seg + __popc((uint32_t)(m2 >> gshift) & 0xffffu) - 1;
-        uint32_t start = rows_sh[gi][slot][s];
-        uint32_t end = (s == 255u) ? 0x10000u : (uint32_t)rows_sh[gi][slot][(s + 1) & 255];
-        x = (end - start) * (x >> 16) + xslot - start;
-        if (x < RANS_L) {
-            if (wpos >= my_len) { err = -25; return false; }
-            uint32_t w = __shfl(win0, (int)(wpos - wbase), GROUP);
-            x = (x << 16) | w;
-            ++wpos;
-            if (wpos - wbase == 16) {                       // first half consumed: slide the window
-                win0 = win1;
-                wbase += 16;
-                win1 = fetch(wbase + 16 + t);
-            }
-        }
-        if (t == 0) dst[i] = (int16_t)s;
-        return true;
-    };
-
-    if (b < e) {
-        // validate the prior indices of this stream once (row_of clamps, this reports)
-        for (uint32_t l = b / M + t; l < (e + M - 1) / M; l += GROUP) {
-            int k = img_idx[l];
-            if (k < 0 || k >= g.K) err = -23;
-        }
-        if (__ballot(err != 0) >> gshift & 0xffffu) err = -23;
+        heads = heads_nx;
     }
-    if (!err && b < e) {
-        RowRegs ra = load_row(next_row(), t);
-        RowRegs rb = load_row(next_row(), t);
-        stage(0, ra);
-        ra = load_row(next_row(), t);
-        uint32_t i = b;
-        // invariant at the top: LDS slot (i-b)&3 holds row i; rb holds row i+1; ra holds row i+2
-        while (i < e) {
-            int s0 = (int)((i - b) & (RING - 1));
-            stage((s0 + 1) & (RING - 1), rb);
-            rb = load_row(next_row(), t);
-            if (!decode_one(i, s0)) break;
-            ++i;
-            if (i >= e) break;
-            int s1 = (int)((i - b) & (RING - 1));
-            stage((s1 + 1) & (RING - 1), ra);
-            ra = load_row(next_row(), t);
-            if (!decode_one(i, s1)) break;
-            ++i;
-        }
-    }
-    if (!err && (x != RANS_L || wpos != my_len)) err = -26;
-    if (err && t == 0) atomicMin(&status[img], err);
+    if (len && !err && (x != RANS_L || wpos != my_len)) err = -26;
+    if (err && live && t == 0) atomicMin(&status[img], err);
 }
 
 int check_geometry(mpc_ctx *ctx, Geometry &g, int K, int M, int L, int n_images, int64_t n_loc, int n_streams,
@@ -538,12 +621,20 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     MPC_REQUIRE(ctx, ((uintptr_t)in % 4) == 0 && in_stride % 4 == 0, "rans_decode: in must be 4-byte aligned with a stride multiple of 4");
     int64_t G = (int64_t)n_images * n_streams;
     MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * n_images, ctx->stream));
-    if (L == 257)
-        decode_streams_lds_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
-            g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
-    else
+    if (L == 257) {
+        // aligned copy of the table for the LDS-DMA row loads (rebuilt per call: the caller may have changed the table)
+        const int64_t rows = (int64_t)K * M;
+        void *aligned = mpc_ctx_scratch(ctx, (size_t)rows * DMA_PITCH * sizeof(uint16_t));
+        if (!aligned) return MPC_EHIP;
+        align_rows_kernel<<<dim3((unsigned)mpc_cdiv(rows * DMA_PITCH, 256)), dim3(256), 0, ctx->stream>>>(
+            (const uint16_t *)table, rows, L, (uint16_t *)aligned);
+        MPC_CHECK_LAUNCH(ctx, "rans align_rows");
+        decode_streams_dma_kernel<<<dim3((unsigned)mpc_cdiv(G, 4)), dim3(128), 0, ctx->stream>>>(
+            g, (const uint16_t *)aligned, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+    } else {
         decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
             g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+    }
     MPC_CHECK_LAUNCH(ctx, "rans decode_streams");
     return MPC_OK;
 }
