@@ -175,11 +175,26 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
             dec, st = ops.rans_decode(self.entropy_table, idx.reshape(-1), out, nbytes, n_images, n_streams, lps)
             if int(st.min().item()) < 0 or not torch.equal(dec.view(-1), sym.reshape(-1)):
                 raise RuntimeError("entropy_encode error: decoded symbols do not match")
-        st_cpu, nb = status.cpu(), nbytes.cpu().tolist()
-        if int(st_cpu.min()) < 0:
-            raise _lib.MpcError(f"rANS encoder reported {st_cpu.tolist()} (symbol outside the table or zero frequency)")
-        host = out[:, :max(nb)].cpu().numpy()          # only the used part of the worst-case-sized buffer
+        # one small copy for (sizes, status), then only the used part of the worst-case-sized buffer, both into
+        # page-locked staging memory
+        meta = torch.cat([nbytes, status.to(torch.int64)]).to("cpu", non_blocking=False).tolist()
+        nb, st = meta[:n_images], meta[n_images:]
+        if min(st) < 0:
+            raise _lib.MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
+        used = max(nb)
+        stage = self._staging(n_images * used)[:n_images * used].view(n_images, used)
+        stage.copy_(out[:, :used], non_blocking=True)
+        torch.cuda.current_stream(out.device).synchronize()
+        host = stage.numpy()
         return [host[i, :nb[i]].tobytes() for i in range(n_images)], (n_streams, lps)
+
+    def _staging(self, nbytes):
+        """Page-locked host buffer of at least nbytes (uint8), reused between calls."""
+        buf = getattr(self, "_stage_buf", None)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+            self._stage_buf = buf
+        return buf
 
     def encode_batch(self, input_image, entropy_coding=True):
         """Batched encode: -> (list of byte strings | int16 symbols [B, h*w*M], idx int32 [B, h*w], h, w)."""
@@ -222,11 +237,12 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         if any(int(hd[1]) != n_streams or int(hd[3]) != sps for hd in heads):
             raise ValueError("decode_batch: all streams of a batch must share one stream geometry")
         stride = (max(len(s) for s in streams) + 3) // 4 * 4
-        host = np.zeros((B, stride), np.uint8)
+        stage = self._staging(B * stride)[:B * stride].view(B, stride)   # bytes past a stream's end are never read
+        host = stage.numpy()
         for i, s in enumerate(streams):
             host[i, :len(s)] = np.frombuffer(s, np.uint8)
-        data = torch.from_numpy(host).to(dev)
-        nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64, device=dev)
+        data = stage.to(dev, non_blocking=True)
+        nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64).to(dev, non_blocking=True)
         idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
         sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, sps // M)
         if int(status.min().item()) < 0:

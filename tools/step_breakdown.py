@@ -8,7 +8,8 @@ from tests import synth
 
 torch.set_grad_enabled(False)
 dev = torch.device("cuda:0")
-model = ca.init_model("ManyPriors", dev, out_channel_N=192, out_channel_M=256, num_distributions=64)
+model = ca.init_model("ManyPriors", dev, out_channel_N=192, out_channel_M=256, num_distributions=64,
+                      analysis_precision="f16x3", synthesis_precision="fp16")
 model.load_state_dict(synth.manypriors_state_dict(234)); model.eval()
 x = synth.rand_image(1000, 24, 512, 768).to(dev)
 T = {}
