@@ -10,8 +10,9 @@ with the input batch already resident in HBM.  value = megapixels (B*H*W of the 
 ranks.  Images are independent, so N GPUs run N independent batches (weak scaling, no data-path collective);
 the only collective is one all-reduce of a 16-double statistics vector per step.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (the f32-MFMA implicit-GEMM conv with fused
-GDN), "cpu_baseline" (the CPU oracle timed on this host on a bounded sample), "kernels" (per-kernel achieved
+Extra objects on the JSON line: "roofline" for the dominant kernel (the implicit-GEMM conv with fused GDN of the
+analysis transform; achieved = algorithmic FLOP / HIP-event time, traffic = bytes per launch from the committed
+counter passes), "cpu_baseline" (the CPU oracle timed on this host on a bounded sample), "kernels" (per-kernel achieved
 rates of the other launches, including the materialised CDF build that the fused coder does not need).
 """
 import argparse
@@ -37,6 +38,21 @@ def kernel_peak(name):
     if name.startswith("conv_igemm_f16"):
         return PEAK_F16_MFMA_TFLOPS, 1
     return PEAK_F32_MFMA_TFLOPS, 1
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/r1_pmc_counters.csv,
+    made by tools/pmc_run.sh: one --pmc pass for FETCH_SIZE, one for WRITE_SIZE; FETCH_SIZE doubled as gfx950 tallies
+    its 128-byte read requests at 64 bytes).  None when the table has no row for the kernel."""
+    import csv
+    path = os.path.join(REPO, "profiles", "r1_pmc_counters.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if kernel in r["Kernel"] and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+                return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+    return None
 
 
 def parse():
@@ -185,7 +201,7 @@ def main():
                    "images_per_gpu": B, "height": H, "width": W, "bpp": bits / (world * B * H * W),
                    "parallelism": f"image-sharded x{world}, stats all-reduce only"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(dom),
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,
                      "avg_launch_ms": d["ms"] / d["calls"], "launches_per_step": d["calls"] / args.steps},
         "kernels": kernels,
