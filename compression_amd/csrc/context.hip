@@ -114,15 +114,43 @@ __global__ void sum_f32_kernel(const float *__restrict__ x, int64_t n, double *_
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
+// 16 bytes per lane and access, two accesses in flight per array; differences squared in fp32, summed in fp64
 __global__ void clamp_sse_kernel(const float *__restrict__ recon, const float *__restrict__ target, int64_t n,
-                                 float *__restrict__ xhat, double *__restrict__ sse) {
+                                 float *__restrict__ xhat, double *__restrict__ sse, int aligned16) {
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float r = recon[i];
-        if (xhat) xhat[i] = fminf(fmaxf(r, 0.0f), 1.0f);
+    const int64_t n4 = aligned16 ? n >> 2 : 0, stride = (int64_t)gridDim.x * blockDim.x;
+    const float4 *r4 = (const float4 *)recon, *t4 = (const float4 *)target;
+    float4 *x4 = (float4 *)xhat;
+    auto one = [&](const float4 &r, int64_t i) {
+        if (xhat) x4[i] = make_float4(fminf(fmaxf(r.x, 0.0f), 1.0f), fminf(fmaxf(r.y, 0.0f), 1.0f),
+                                      fminf(fmaxf(r.z, 0.0f), 1.0f), fminf(fmaxf(r.w, 0.0f), 1.0f));
+    };
+    auto sq = [&](const float4 &r, const float4 &t) {
+        float a = r.x - t.x, b = r.y - t.y, c = r.z - t.z, d = r.w - t.w;
+        acc += (double)(a * a) + (double)(b * b) + (double)(c * c) + (double)(d * d);
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        float4 ra = r4[i], rb = r4[i + stride];
         if (target) {
-            float d = r - target[i];
-            acc += (double)d * (double)d;
+            float4 ta = t4[i], tb = t4[i + stride];
+            sq(ra, ta);
+            sq(rb, tb);
+        }
+        one(ra, i);
+        one(rb, i + stride);
+    }
+    for (; i < n4; i += stride) {
+        float4 ra = r4[i];
+        if (target) sq(ra, t4[i]);
+        one(ra, i);
+    }
+    for (int64_t k = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {   // tail
+        float r = recon[k];
+        if (xhat) xhat[k] = fminf(fmaxf(r, 0.0f), 1.0f);
+        if (target) {
+            float d = r - target[k];
+            acc += (double)(d * d);
         }
     }
     if (sse) {
@@ -162,7 +190,8 @@ int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t
     if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double), ctx->stream));
     int64_t blocks = mpc_cdiv(n, 256 * 4);
     if (blocks > 4096) blocks = 4096;
-    clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev);
+    const int aligned16 = (((uintptr_t)recon | (uintptr_t)target | (uintptr_t)xhat) & 15) == 0;
+    clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev, aligned16);
     MPC_CHECK_LAUNCH(ctx, "clamp_sse");
     return MPC_OK;
 }

@@ -135,6 +135,109 @@ __global__ __launch_bounds__(64 * RGB16_WAVES, 2) void deconv_rgb16_kernel(const
     }
 }
 
+// Variant for base grids whose width is a multiple of 32 (every size the codec pads to): a wave owns 32
+// consecutive pixels of ONE image row, so for each input row offset dy and 64-channel chunk it stages the 34
+// input pixels x0-1 .. x0+32 once, in full 128-byte lines, into a wave-private LDS tile and reads the B operands
+// of the three horizontal taps from there at shifted positions: a third of the vector-memory traffic of the
+// direct form, and whole cache lines per load instruction.  Tile layout: [pixel 34][8 pieces of 16 bytes],
+// piece q of pixel p at column q ^ (p & 7) (conflict-free for the 16-byte reads of 16 consecutive pixels).
+constexpr int ROWS_WAVES = 16;
+constexpr int ROWS_TILE = 32;
+constexpr int ROWS_STAGE_F4 = 34 * 8;      // 16-byte slots of one staging tile
+
+__global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(const Params p, const float4 *__restrict__ wimg,
+                                                                             int nsteps, int64_t ntiles) {
+    extern __shared__ float4 lds[];                        // nsteps * 128 weights, then ROWS_WAVES staging tiles
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nsteps * 128; i += 64 * ROWS_WAVES) lds[i] = wimg[i];
+    __syncthreads();
+
+    const int lane = tid & 63, n = lane & 15, kg = lane >> 4, wave = tid >> 6;
+    float4 *stage = lds + nsteps * 128 + wave * ROWS_STAGE_F4;
+    const int cb = p.cin_blocks;                           // cin / 64
+    const _Float16 *in = (const _Float16 *)p.in;
+    float *out = (float *)p.out;
+    const bool clamp01 = (p.flags & MPC_OUT_CLAMP01) != 0;
+    const int tw = p.Wb / ROWS_TILE;                       // tiles per row
+
+    // staging role of this lane: pieces j = lane + 64 i of the 34 x 8 tile
+    int spx[5], slot[5], sq[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int j = lane + 64 * i;
+        spx[i] = j >> 3;
+        sq[i] = j & 7;
+        slot[i] = spx[i] * 8 + (sq[i] ^ (spx[i] & 7));
+    }
+    // B-operand role: pixel n of sub-tile u, k-group kg; tile pixel index 1 + 16u + n + dx
+    const int64_t per_xcd = (ntiles + NUM_XCD - 1) / NUM_XCD;
+    const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
+    const int64_t t1 = (t0 + per_xcd < ntiles) ? t0 + per_xcd : ntiles;
+    const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * ROWS_WAVES;
+    for (int64_t t = t0 + (int64_t)(blockIdx.x / NUM_XCD) * ROWS_WAVES + wave; t < t1; t += stride) {
+        const int x0 = (int)(t % tw) * ROWS_TILE;
+        const int64_t rowid = t / tw;
+        const int y = (int)(rowid % p.Hb), b = (int)(rowid / p.Hb);
+        const int dy_lo = (y == 0) ? 0 : -1, dy_hi = (y == p.Hi - 1) ? 0 : 1;
+        const int niter = (dy_hi - dy_lo + 1) * cb;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+        auto load_stage = [&](int it, float4 (&dst)[5]) {
+            const int dyi = it / cb, chunk = it - dyi * cb;
+            const _Float16 *rowp = in + (((int64_t)b * p.Hi + y + dy_lo + dyi) * p.Wi + x0 - 1) * p.Cs + chunk * 64;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int gx = x0 - 1 + spx[i];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((i < 4 || spx[i] < 34) && gx >= 0 && gx < p.Wi) v = *(const float4 *)(rowp + (int64_t)spx[i] * p.Cs + sq[i] * 8);
+                dst[i] = v;
+            }
+        };
+        float4 sreg[5];
+        load_stage(0, sreg);
+        for (int it = 0; it < niter; ++it) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                if (i < 4 || spx[i] < 34) stage[slot[i]] = sreg[i];
+            if (it + 1 < niter) load_stage(it + 1, sreg);
+            const int dyi = it / cb, chunk = it - dyi * cb;
+            const int tap0 = (dy_lo + dyi + 1) * 3;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int s = (tap0 + dx) * cb + chunk;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const half8 a = as_half8(lds[(s * 2 + ks) * 64 + lane]);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int px = 16 * u + n + dx;    // = 1 + 16u + n + (dx - 1)
+                        const half8 bv = as_half8(stage[px * 8 + ((ks * 4 + kg) ^ (px & 7))]);
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv, acc[u], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // lane (n, kg) holds rows 4kg..4kg+3 of pixel n: (co, ypar) = (kg, 0) in registers 0,1 and (kg, 1) in 2,3
+        if (kg < p.cout) {
+            const float bias = p.bias[kg];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int yp = 0; yp < 2; ++yp) {
+                    float v0 = acc[u][2 * yp] + bias, v1 = acc[u][2 * yp + 1] + bias;
+                    if (clamp01) {
+                        v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
+                        v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
+                    }
+                    float *o = out + (((int64_t)b * p.cout + kg) * p.Ho + 2 * y + yp) * p.Wo + 2 * (x0 + 16 * u + n);
+                    *(float2 *)o = make_float2(v0, v1);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // bytes of the packed A image
@@ -157,6 +260,21 @@ int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     if (lds > 48 * 1024 && !attr_set) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)deconv_rgb16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
+    }
+    if (p.Wb % ROWS_TILE == 0 && p.Hb == p.Hi && p.Wb == p.Wi) {
+        const size_t lds_rows = lds + (size_t)ROWS_WAVES * ROWS_STAGE_F4 * sizeof(float4);
+        static bool attr_rows = false;
+        if (!attr_rows) {
+            MPC_HIP(ctx, hipFuncSetAttribute((const void *)deconv_rgb16_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+            attr_rows = true;
+        }
+        const int64_t nt = p.P / ROWS_TILE;
+        int64_t blocks = mpc_cdiv(nt, ROWS_WAVES);
+        if (blocks > NUM_CU) blocks = NUM_CU;          // persistent: one 16-wave workgroup per CU
+        blocks = xcd_grid(blocks);
+        deconv_rgb16_rows_kernel<<<dim3((unsigned)blocks), dim3(64 * ROWS_WAVES), lds_rows, ctx->stream>>>(p, (const float4 *)c->wpk_rgb16, nsteps, nt);
+        MPC_CHECK_LAUNCH(ctx, "deconv_rgb16_rows");
+        return MPC_OK;
     }
     const int64_t ntiles = mpc_cdiv(p.P, RGB16_TILE);
     // persistent workgroups: two per CU while there is work for them, a multiple of the XCD count

@@ -190,6 +190,25 @@ def test_fp16_layers_against_fp32_reference(dev, ops, cin, act):
     assert err < 4e-3
 
 
+@pytest.mark.parametrize("hw", [(5, 64), (3, 32), (1, 96)])
+def test_fp16_last_layer_row_tiled_kernel(dev, ops, hw):
+    """The fp16 192 -> 3 layer on inputs whose width is a multiple of 32 takes the row-tiled kernel (horizontal
+    taps staged through LDS); odd widths take the direct one.  Both must agree with the fp32 reference."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(hw[0] * 100 + hw[1])
+    x = torch.randn(2, 192, *hw, generator=g)
+    w, b = _w(g, 192, 3, 5, 5, scale=0.02), _w(g, 3, scale=0.5)
+    want = F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1)
+    layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, f16=True)
+    got = layer(nhwc(x).to(dev).half()).cpu()
+    assert got.shape == want.shape
+    err = rel_err(got, want)
+    print(f"fp16 last layer {hw}: rel err {err:.2e}")
+    assert err < 4e-3
+    clamped = layer(nhwc(x).to(dev).half(), clamp01=True).cpu()
+    assert torch.equal(clamped, got.clamp(0, 1))
+
+
 def to_split(x_nhwc, scale=256.0):
     """fp32 NHWC -> S16 split tensor [B,H,W,C/8,16] (hi x8 | lo x8), the format f16x3 layers read."""
     v = (x_nhwc * scale).float()
