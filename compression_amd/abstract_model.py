@@ -130,6 +130,84 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
             {"params": self.bitEstimator_z.parameters(), "lr": lr * 10, "name": "bit_estimator"},
         ]
 
+    # ---- entropy-coded encode / decode (abstract_model.py:370-500) ----------------------------------
+    def _latent_hw(self, H, W):
+        """Spatial size of y and z for an H x W image (four, then two more, stride-2 k5 p2 convolutions)."""
+        def down(n, times):
+            for _ in range(times):
+                n = (n + 1) // 2
+            return n
+        return (down(H, 4), down(W, 4)), (down(H, 6), down(W, 6))
+
+    def _main_L(self):
+        return int((-self.min_feat_gaussian + self.max_feat_gaussian) / self.q_intv + 2)
+
+    def _main_rows(self, zhat):
+        """Per-element int16 Laplace(0, sigma) CDF rows of the main stream, in NHWC element order, as a
+        [n_loc, M, L] table (abstract_model.py:402-416; the rows are computed on the device, 514 bytes per
+        symbol, and never leave it)."""
+        sigma = self.priorDecoder.forward_nhwc(zhat)
+        L = self._main_L()
+        rows = ops.laplace_cdf_rows(sigma.reshape(-1), self.min_feat_gaussian - 0.5, L, self.precision)
+        return sigma, rows.view(-1, self.out_channel_M, L)
+
+    def encode(self, input_image, entropy_coding=True):
+        """One image -> [main string, z string, H, W] (abstract_model.py:370-454); with entropy_coding=False the
+        two int16 symbol vectors in the reference's orders (y: NCHW flattened, z: location-major).  The strings are
+        MRS1 rANS containers, not torchac bytes.  H and W must be multiples of 64."""
+        self._require_eval()
+        x = input_image.contiguous()
+        B, _, H, W = x.shape
+        if B != 1:
+            raise ValueError("encode() handles one image per call like the reference")
+        y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
+        _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
+        sym_y, clamp_y = ops.latent_to_symbols(yhat, self.min_feat_gaussian, self.q_intv, self._main_L() - 1)
+        sym_z, clamp_z = ops.latent_to_symbols(zhat, self.min_feat, self.q_intv, self._n_targets() - 1)
+        if int(clamp_y.item()) or int(clamp_z.item()):
+            raise ValueError("encode: a latent falls outside the CDF tables' range "
+                             f"[{self.min_feat_gaussian},{self.max_feat_gaussian}] / [{self.min_feat},{self.max_feat}]")
+        _, h, w, M = yhat.shape
+        if not entropy_coding:
+            return sym_y.view(h, w, M).permute(2, 0, 1).reshape(-1), sym_z.reshape(-1)
+        if H % 64 or W % 64:
+            raise ValueError("entropy-coded encode needs H and W to be multiples of 64")
+        self.update_entropy_table()                     # small (N x L); keeps the z table in step with the parameters
+        sigma, rows = self._main_rows(zhat)
+        n_loc = h * w
+        idx = torch.arange(n_loc, dtype=torch.int32, device=x.device)       # every location has a table of its own
+        est = float(ops.laplace_bits_total(yhat, sigma).item()) / 8
+        main = ops.rans_encode_to_bytes(rows, idx, sym_y, 1, est)[0]
+        zt = self.z_entropy_table.view(1, self.out_channel_N, -1).contiguous()
+        n_zloc = sym_z.numel() // self.out_channel_N
+        zidx = torch.zeros(n_zloc, dtype=torch.int32, device=x.device)
+        zstr = ops.rans_encode_to_bytes(zt, zidx, sym_z, 1, float(sym_z.numel()))[0]
+        return [main, zstr, H, W]
+
+    def decode(self, bitstream):
+        """[main string, z string, H, W] -> reconstruction (NCHW, unclamped); a tensor is taken as the latent and
+        only goes through g_s.  (The reference's decode, abstract_model.py:456-500, stops in a breakpoint and
+        mis-sizes z; this one inverts encode().)"""
+        if isinstance(bitstream, torch.Tensor):
+            return self.Decoder(bitstream)
+        self._require_eval()
+        main, zstr, H, W = bitstream
+        if H % 64 or W % 64:
+            raise ValueError("decode needs H and W to be multiples of 64")
+        dev = next(self.parameters()).device
+        self.update_entropy_table()
+        (h, w), (zh, zw) = self._latent_hw(H, W)
+        N, M = self.out_channel_N, self.out_channel_M
+        zt = self.z_entropy_table.view(1, N, -1).contiguous()
+        sym_z = ops.rans_decode_from_bytes(zt, torch.zeros(zh * zw, dtype=torch.int32, device=dev), [zstr])
+        zhat = ops.symbols_to_latent(sym_z.view(1, zh, zw, N), self.min_feat, self.q_intv)
+        _, rows = self._main_rows(zhat)
+        if rows.shape[0] != h * w:
+            raise ValueError("decode: the z string does not match the image size")
+        sym_y = ops.rans_decode_from_bytes(rows, torch.arange(h * w, dtype=torch.int32, device=dev), [main])
+        yhat = ops.symbols_to_latent(sym_y.view(1, h, w, M), self.min_feat_gaussian, self.q_intv)
+        return self.Decoder.forward_nhwc(yhat)
+
     def compress(self, input_image):
         """-> (round(y), round(z)) as NCHW tensors (abstract_model.py:733-738)."""
         y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(input_image.contiguous(), 4), round_out=True)

@@ -280,6 +280,44 @@ def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbyt
     return sym, status
 
 
+def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_images: int,
+                         est_bytes_per_image: float) -> List[bytes]:
+    """Codes n_images equally shaped images and returns their MRS1 containers as byte strings."""
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image)
+    out, nbytes, status = rans_encode(table, idx.reshape(-1), sym.reshape(-1), n_images, n_streams, lps)
+    meta = torch.cat([nbytes, status.to(torch.int64)]).cpu().tolist()
+    nb, st = meta[:n_images], meta[n_images:]
+    if min(st) < 0:
+        raise MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
+    host = out[:, :max(nb)].cpu().numpy()
+    return [host[i, :nb[i]].tobytes() for i in range(n_images)]
+
+
+def rans_decode_from_bytes(table: torch.Tensor, idx: torch.Tensor, streams: List[bytes]) -> torch.Tensor:
+    """Inverse of rans_encode_to_bytes: -> int16 symbols [n_images, n_loc*M].  The stream geometry is read from the
+    containers' headers (all images of the call must share it)."""
+    import numpy as np
+    K, M, L = table.shape
+    B = len(streams)
+    heads = [np.frombuffer(s[:16], dtype="<u4") for s in streams]
+    n_streams, sps = int(heads[0][1]), int(heads[0][3])
+    if any(len(s) < 16 for s in streams) or any(int(h[1]) != n_streams or int(h[3]) != sps for h in heads):
+        raise ValueError("rans_decode_from_bytes: truncated container or differing stream geometry")
+    stride = (max(len(s) for s in streams) + 3) // 4 * 4
+    host = np.zeros((B, stride), np.uint8)
+    for i, s in enumerate(streams):
+        host[i, :len(s)] = np.frombuffer(s, np.uint8)
+    dev = table.device
+    data = torch.from_numpy(host).to(dev)
+    nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64, device=dev)
+    sym, status = rans_decode(table, idx.reshape(-1), data, nbytes, B, n_streams, sps // M)
+    if int(status.min().item()) < 0:
+        raise MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
+    return sym
+
+
 # ---- hyperprior likelihoods -----------------------------------------------------------------------
 def laplace_bits_total(yhat: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
     _dev(yhat, torch.float32, "yhat"); _dev(sigma, torch.float32, "sigma")

@@ -238,6 +238,39 @@ def test_hyperprior_forward(dev, golden):
     assert d.max().item() <= 1 and (d != 0).float().mean().item() < 2e-3
 
 
+def test_hyperprior_entropy_coded_round_trip(dev, golden):
+    """Hyperprior encode -> [main string, z string, H, W] -> decode: symbols equal the reference's
+    (entropy_coding=False capture), the decode reproduces g_s(round(y)) exactly, and the coded size is close to the
+    model's own bit estimate."""
+    import compression_amd as ca
+    g = golden("encode_hyperprior")
+    m = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M, synthesis_precision="fp32")
+    m.load_state_dict(synth.hyperprior_state_dict(236, N, M))
+    m.eval()
+    x = synth.smooth_image(4, 1, 128, 192).to(dev)
+    ys, zs = m.encode(x, entropy_coding=False)
+    assert (ys.cpu() != torch.from_numpy(g["y_sym"])).float().mean().item() <= 1e-5      # rounding ties only
+    assert torch.equal(zs.cpu(), torch.from_numpy(g["z_sym"]))
+    main, zstr, H, W = m.encode(x)
+    assert (H, W) == (128, 192) and main[:4] == b"MRS1" and zstr[:4] == b"MRS1"
+    recon = m.decode([main, zstr, H, W])
+    yq, _ = m.compress(x)
+    want = m.decode(yq)
+    assert torch.equal(recon, want)
+    out = m(x)
+    est_bits = float(out["bpp"]) * H * W
+    coded_bits = 8 * (len(main) + len(zstr))
+    print(f"hyperprior: coded {coded_bits} bits, estimated {est_bits:.0f}")
+    assert coded_bits < est_bits * 1.03 + 8 * 64
+    with pytest.raises(_lib_error()):
+        m.decode([main[:len(main) // 2], zstr, H, W])
+
+
+def _lib_error():
+    from compression_amd import MpcError
+    return (MpcError, ValueError)
+
+
 def test_training_mode_and_cpu_are_refused(model, dev):
     from compression_amd import MpcError
     model.train(True)
