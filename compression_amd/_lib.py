@@ -45,6 +45,9 @@ SIGNATURES = {
     "mpc_symbols_to_latent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mpc_sum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_clamp_sse": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mpc_ssim_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_int, c_float, c_float,
+                               c_void_p, c_void_p]),
+    "mpc_avg_pool2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mpc_bitparm_cdf_table": (c_int, [c_void_p, POINTER(c_void_p), c_int64, c_float, c_int, c_void_p]),
     "mpc_bitparm_cdf_eval": (c_int, [c_void_p, POINTER(c_void_p), c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "mpc_renorm_cast_cdf": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -3,7 +3,7 @@
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 out="$here/../libmpc.so"
-srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip conv_igemm_f16.hip conv_igemm_x3.hip conv_rgb_out_f16.hip)
+srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip conv_igemm_f16.hip conv_igemm_x3.hip conv_rgb_out_f16.hip metrics.hip)
 objs=()
 mkdir -p "$here/build"
 pids=()

@@ -3,7 +3,7 @@
 The reference has no distributed code (one process, one device).  The codec path has no cross-image state, so N
 GPUs run N independent shards; the only exchange is the sum of the evaluation statistics that the reference's
 test harness accumulates per image (src/compression/tests.py:439-460): bits, pixels, squared error, PSNR,
-image count, bytes, seconds.  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
+MS-SSIM (and its dB form), image count, bytes, seconds.  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
 GPU box, "gloo" for CPU rehearsal).
 """
 import math
@@ -11,7 +11,8 @@ from typing import Dict, List
 
 import torch
 
-STAT_KEYS = ("bits", "pixels", "sq_err", "psnr_sum", "images", "bytes", "seconds", "side_bits")
+STAT_KEYS = ("bits", "pixels", "sq_err", "psnr_sum", "images", "bytes", "seconds", "side_bits", "msssim_sum",
+             "msssim_db_sum")
 VECTOR_LEN = 16
 
 
@@ -27,11 +28,12 @@ class StatsAccumulator:
         self.vec = torch.zeros(VECTOR_LEN, dtype=torch.float64, device=device)
 
     def add_image(self, bits: float, pixels: int, sq_err: float, nbytes: int = 0, seconds: float = 0.0,
-                  side_bits: float = 0.0):
+                  side_bits: float = 0.0, msssim: float = 0.0):
         mse = sq_err / max(pixels * 3, 1)
         psnr = 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")
         row = dict(bits=bits, pixels=pixels, sq_err=sq_err, psnr_sum=psnr, images=1, bytes=nbytes, seconds=seconds,
-                   side_bits=side_bits)
+                   side_bits=side_bits, msssim_sum=msssim,
+                   msssim_db_sum=-10.0 * math.log10(1.0 - msssim) if 0.0 < msssim < 1.0 else 0.0)
         for i, k in enumerate(STAT_KEYS):
             self.vec[i] += row[k]
 
@@ -45,4 +47,5 @@ class StatsAccumulator:
         v = {k: float(self.vec[i]) for i, k in enumerate(STAT_KEYS)}
         n = max(v["images"], 1.0)
         return {**v, "bpp": (v["bits"] + v["side_bits"]) / max(v["pixels"], 1.0), "psnr": v["psnr_sum"] / n,
+                "msssim": v["msssim_sum"] / n, "msssimDB": v["msssim_db_sum"] / n,
                 "mse": v["sq_err"] / max(v["pixels"] * 3, 1.0)}

@@ -280,6 +280,34 @@ def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbyt
     return sym, status
 
 
+# ---- image-quality statistics ------------------------------------------------------------------------
+def ssim_stats(x: torch.Tensor, y: torch.Tensor, window: Sequence[float], C1: float, C2: float):
+    """x, y NCHW fp32 -> (mean SSIM map, mean contrast-structure map) per (image, channel), float64 [B, C]."""
+    _dev(x, torch.float32, "x"); _dev(y, torch.float32, "y")
+    if x.shape != y.shape or x.dim() != 4:
+        raise MpcError("ssim_stats: x and y must be NCHW tensors of one shape")
+    B, C, H, W = x.shape
+    n = len(window)
+    ss = torch.empty(B * C, dtype=torch.float64, device=x.device)
+    cs = torch.empty(B * C, dtype=torch.float64, device=x.device)
+    win = (ctypes.c_float * n)(*[float(v) for v in window])
+    with _timed("ssim_stats", bytes=2.0 * x.numel() * 4):
+        context_for(x.device).call("mpc_ssim_stats", ptr(x), ptr(y), B * C, H, W, win, n, ctypes.c_float(C1), ctypes.c_float(C2),
+                                   ptr(ss), ptr(cs))
+    area = float((H - n + 1) * (W - n + 1))
+    return (ss / area).view(B, C), (cs / area).view(B, C)
+
+
+def avg_pool2(x: torch.Tensor) -> torch.Tensor:
+    """F.avg_pool2d(x, kernel_size=2, padding=(H % 2, W % 2)) of an NCHW fp32 tensor."""
+    _dev(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    Ho, Wo = (H + 2 * (H % 2) - 2) // 2 + 1, (W + 2 * (W % 2) - 2) // 2 + 1
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    context_for(x.device).call("mpc_avg_pool2", ptr(x), B * C, H, W, ptr(out))
+    return out
+
+
 def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_images: int,
                          est_bytes_per_image: float) -> List[bytes]:
     """Codes n_images equally shaped images and returns their MRS1 containers as byte strings."""

@@ -74,6 +74,17 @@ int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev);
 int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat,
                   double *sse_dev);
 
+/* ---- image-quality statistics of the reference's test harness (src/compression/tests.py:393-418) ------------- */
+/* Sums over the valid region ((H-win_size+1) x (W-win_size+1)) of the SSIM map and of the contrast-structure map
+ * of every plane of x and y ([planes][H][W] fp32, planes = batch*channels), with the separable window `window`
+ * (host array of win_size floats, odd, <= 15) and the stabilisers C1 = (K1*data_range)^2, C2 = (K2*data_range)^2.
+ * The caller divides by the region size.  Replaces _ssim (src/common/extlibs/pt_ms_ssim.py:41-84). */
+int mpc_ssim_stats(mpc_ctx *ctx, const float *x, const float *y, int planes, int H, int W, const float *window,
+                   int win_size, float C1, float C2, double *ssim_sum_dev, double *cs_sum_dev);
+/* F.avg_pool2d(kernel_size=2, padding=(H%2, W%2)) between the MS-SSIM scales (pt_ms_ssim.py:205-207):
+ * out [planes][Ho][Wo], Ho = (H + 2*(H%2) - 2)/2 + 1. */
+int mpc_avg_pool2(mpc_ctx *ctx, const float *in, int64_t planes, int H, int W, float *out);
+
 /* ---- learned CDF tables -------------------------------------------------------------------- */
 /* Float CDF table of a (multi-head) factorised prior evaluated at targets first_target + s, s < L:
  * table_f[row][s], row < n_rows, with the 4-layer Bitparm chain of bitEstimator.py:136-141.

@@ -371,3 +371,58 @@ def hyperprior_forward(x: torch.Tensor, sd: SD) -> dict:
         "bpp_feature": bits_y / npix, "bpp_sidestring": bits_z / npix,
         "bpp": bits_y / npix + bits_z / npix,
     }
+
+# ----------------------------------------------------------------------------
+# Image-quality statistics  (src/common/extlibs/pt_ms_ssim.py:8-216, src/compression/tests.py:393-418)
+# ----------------------------------------------------------------------------
+def gauss_window(size: int = 11, sigma: float = 1.5) -> torch.Tensor:
+    """pt_ms_ssim.py:8-23."""
+    coords = torch.arange(size).to(dtype=torch.float)
+    coords -= size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def _gaussian_filter(x: torch.Tensor, win: torch.Tensor) -> torch.Tensor:
+    """Separable valid filtering, width first then height (pt_ms_ssim.py:26-38)."""
+    C = x.shape[1]
+    w = win.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+    out = F.conv2d(x, w, stride=1, padding=0, groups=C)
+    return F.conv2d(out, w.transpose(2, 3), stride=1, padding=0, groups=C)
+
+
+def ssim_maps(X: torch.Tensor, Y: torch.Tensor, win: torch.Tensor, data_range: float = 1.0,
+              K: Tuple[float, float] = (0.01, 0.03)) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(mean SSIM, mean contrast-structure) per (image, channel). pt_ms_ssim.py:41-84."""
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mu1, mu2 = _gaussian_filter(X, win), _gaussian_filter(Y, win)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = _gaussian_filter(X * X, win) - mu1_sq
+    sigma2_sq = _gaussian_filter(Y * Y, win) - mu2_sq
+    sigma12 = _gaussian_filter(X * Y, win) - mu1_mu2
+    cs_map = (2 * sigma12 + C2) / (sigma1_sq + sigma2_sq + C2)
+    ssim_map = ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return torch.flatten(ssim_map, 2).mean(-1), torch.flatten(cs_map, 2).mean(-1)
+
+
+def ms_ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """pt_ms_ssim.py:144-216 with the default window and weights, size_average=True."""
+    weights = torch.FloatTensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+    win = gauss_window()
+    mcs = []
+    for i in range(5):
+        ssim_pc, cs = ssim_maps(X, Y, win, data_range)
+        if i < 4:
+            mcs.append(torch.relu(cs))
+            padding = (X.shape[2] % 2, X.shape[3] % 2)
+            X = F.avg_pool2d(X, kernel_size=2, padding=padding)
+            Y = F.avg_pool2d(Y, kernel_size=2, padding=padding)
+    ssim_pc = torch.relu(ssim_pc)
+    val = torch.prod(torch.stack(mcs + [ssim_pc], dim=0) ** weights.view(-1, 1, 1), dim=0)
+    return val.mean()
+
+
+def psnr(xhat: torch.Tensor, x: torch.Tensor) -> float:
+    """tests.py:393-398."""
+    mse = F.mse_loss(xhat, x)
+    return (10 * (torch.log(1.0 / mse) / math.log(10))).item()

@@ -71,7 +71,41 @@ def load(model, sd):
     return model.train(False)
 
 
+def metric_inputs(case):
+    """(reconstruction, ground truth) pairs of the image-statistics fixture: an even and an odd size (the odd one
+    exercises the padded 2x pooling), three images' worth of planes."""
+    if case == 0:
+        gt = synth.smooth_image(21, 2, 192, 256)
+    else:
+        gt = synth.smooth_image(22, 1, 211, 177)
+    g = torch.Generator().manual_seed(100 + case)
+    rec = (gt + 0.03 * torch.randn(gt.shape, generator=g)).clamp(0, 1)
+    return rec, gt
+
+
+def metrics_fixture():
+    """MS-SSIM / SSIM / PSNR of the reference (src/common/extlibs/pt_ms_ssim.py, tests.py:393-412)."""
+    import_reference()
+    from common.extlibs import pt_ms_ssim
+    torch.set_grad_enabled(False)
+    out = {}
+    for case in (0, 1):
+        rec, gt = metric_inputs(case)
+        win = pt_ms_ssim._fspecial_gauss_1d(11, 1.5).repeat(3, 1, 1, 1)
+        s_pc, cs = pt_ms_ssim._ssim(rec, gt, data_range=1.0, win=win, size_average=False)
+        mse = torch.nn.functional.mse_loss(rec, gt)
+        out[f"ssim_pc{case}"] = s_pc.numpy()
+        out[f"cs{case}"] = cs.numpy()
+        out[f"ssim{case}"] = np.float32(pt_ms_ssim.ssim(rec, gt, data_range=1.0))
+        out[f"msssim{case}"] = np.float32(pt_ms_ssim.ms_ssim(rec, gt, data_range=1.0, size_average=True))
+        out[f"psnr{case}"] = np.float64((10 * (torch.log(1.0 / mse) / np.log(10))).item())
+    np.savez_compressed(os.path.join(OUT, "image_metrics.npz"), **out)
+    print({k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        return metrics_fixture()
     mc, am, b18, tc = import_reference()
     cpu = torch.device("cpu")
     torch.set_grad_enabled(False)

@@ -271,6 +271,37 @@ def _lib_error():
     return (MpcError, ValueError)
 
 
+def test_image_metrics_on_device(dev, golden):
+    """Device SSIM / MS-SSIM / PSNR (the statistics test_dir accumulates) against the reference capture; fp32
+    filtering in another summation order, so to 1e-5, not to the bit."""
+    from compression_amd import pt_ms_ssim
+    from tests.golden.make_golden import metric_inputs
+    g = golden("image_metrics")
+    for case in (0, 1):
+        rec, gt = metric_inputs(case)
+        rec, gt = rec.to(dev), gt.to(dev)
+        s_pc, cs = ops_mod().ssim_stats(rec, gt, pt_ms_ssim._fspecial_gauss_1d(11, 1.5).tolist(), 0.01 ** 2, 0.03 ** 2)
+        assert np.abs(s_pc.cpu().numpy() - g[f"ssim_pc{case}"]).max() < 1e-5
+        assert np.abs(cs.cpu().numpy() - g[f"cs{case}"]).max() < 1e-5
+        assert abs(float(pt_ms_ssim.ssim(rec, gt)) - float(g[f"ssim{case}"])) < 1e-5
+        assert abs(float(pt_ms_ssim.ms_ssim(rec, gt)) - float(g[f"msssim{case}"])) < 1e-5
+        st = pt_ms_ssim.image_stats(rec, gt, bpp=0.5, train_lambda=4096, visual_loss=1e-3)
+        assert abs(st["psnr"] - float(g[f"psnr{case}"])) < 1e-4
+        assert abs(st["msssimDB"] - (-10 * np.log10(1 - float(g[f"msssim{case}"])))) < 1e-2
+        assert st["combined_loss"] == pytest.approx(4096 * 1e-3 + 0.5)
+    # pooling with odd sizes pads like F.avg_pool2d(kernel_size=2, padding=(H % 2, W % 2))
+    x = torch.rand(2, 3, 7, 10)
+    want = torch.nn.functional.avg_pool2d(x, kernel_size=2, padding=(1, 0))
+    assert torch.allclose(ops_mod().avg_pool2(x.to(dev)).cpu(), want, atol=1e-7)
+    with pytest.raises(AssertionError):
+        pt_ms_ssim.ms_ssim(torch.rand(1, 3, 100, 300, device=dev), torch.rand(1, 3, 100, 300, device=dev))
+
+
+def ops_mod():
+    from compression_amd import ops
+    return ops
+
+
 def test_training_mode_and_cpu_are_refused(model, dev):
     from compression_amd import MpcError
     model.train(True)
