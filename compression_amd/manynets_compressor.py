@@ -227,6 +227,19 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
             pt_helpers.compress_png(indices.view(1, h, w).cpu().numpy(), out_fpath + ".png")
         return [bitstream, indices, h, w]
 
+    def encode_to_archive(self, input_image, path):
+        """One image -> one self-describing file (main string + the cheapest coding of the prior-index map + the
+        image size; the reference's TODO at manynets_compressor.py:278).  Returns the file size in bytes."""
+        bitstream, indices, h, w = self.encode(input_image)
+        H, W = input_image.shape[-2:]
+        return pt_helpers.write_archive(path, bitstream, indices.view(h, w), H, W, try_png=TRY_PNG_SIDESTRING)
+
+    def decode_archive(self, path):
+        """File written by encode_to_archive -> reconstruction (NCHW, unclamped)."""
+        bitstream, indices, H, W = pt_helpers.read_archive(path)
+        h, w = indices.shape
+        return self.decode([bitstream, indices, h, w])
+
     def decode_batch(self, streams: List[bytes], idx, h: int, w: int):
         """List of MRS1 byte strings + idx [B, h*w] -> reconstruction NCHW (unclamped)."""
         self._ensure_tables()

@@ -131,3 +131,87 @@ def get_num_bits(tensor, integers=False, compression="lzma", try_png=True):
     if integers:
         num_bits = min(num_bits, arr.size * bits_per_value(arr))
     return num_bits
+
+
+# ---- one self-describing file per image ----------------------------------------------------------------
+# The reference writes a pair of files (<name>.mbs = torchac bytes, <name>.png = prior-index map,
+# manynets_compressor.py:279-311) and leaves "one archive" as a TODO (:278).  MPA1 is that archive:
+#   "MPA1" | u16 version | u16 side codec | u32 H | u32 W | u16 h | u16 w | u8 bits per index | u32 side bytes |
+#   u32 main bytes | side string | main string (MRS1)
+# side codec: 0 all-zero map (no bytes), 1 raw, 2 LZMA, 3 PNG, 4 fixed-length packed bits -- the candidates of
+# get_num_bits; the smallest is stored, so the archive's side string costs exactly bpp_sidestring.
+ARCHIVE_MAGIC = b"MPA1"
+SIDE_ZERO, SIDE_RAW, SIDE_LZMA, SIDE_PNG, SIDE_FIXED = 0, 1, 2, 3, 4
+_ARCHIVE_HEAD = struct.Struct("<4sHHIIHHBII")
+
+
+def _pack_fixed(arr: np.ndarray, nbits: int) -> bytes:
+    bits = ((arr.reshape(-1, 1).astype(np.uint32) >> np.arange(nbits - 1, -1, -1, dtype=np.uint32)) & 1).astype(np.uint8)
+    return np.packbits(bits.reshape(-1)).tobytes()
+
+
+def _unpack_fixed(data: bytes, n: int, nbits: int) -> np.ndarray:
+    bits = np.unpackbits(np.frombuffer(data, np.uint8))[:n * nbits].reshape(n, nbits).astype(np.uint32)
+    return (bits << np.arange(nbits - 1, -1, -1, dtype=np.uint32)).sum(1)
+
+
+def encode_side_string(indices, try_png=True):
+    """[h, w] integer map -> (codec, bits per index, bytes): the cheapest of get_num_bits' candidates."""
+    idx = torch.as_tensor(indices).detach().cpu()
+    if idx.dim() != 2:
+        raise ValueError("the prior-index map of one image is [h, w]")
+    if int(idx.min()) == 0 and int(idx.max()) == 0:
+        return SIDE_ZERO, 0, b""
+    arr = to_smallest_type(idx, integers=True).numpy()
+    nbits = bits_per_value(arr)
+    cands = [(SIDE_RAW, arr.tobytes()), (SIDE_LZMA, lzma.compress(arr.tobytes())), (SIDE_FIXED, _pack_fixed(arr, nbits))]
+    if try_png:
+        cands.append((SIDE_PNG, png_bytes(arr[None])))
+    # the packed candidate is charged its exact bit count (like get_num_bits), the others their byte size
+    cost = lambda c: arr.size * nbits if c[0] == SIDE_FIXED else 8 * len(c[1])
+    codec, data = min(cands, key=cost)
+    return codec, nbits, data
+
+
+def decode_side_string(codec, nbits, data, h, w):
+    n = h * w
+    if codec == SIDE_ZERO:
+        return np.zeros((h, w), np.int64)
+    if codec == SIDE_PNG:
+        out = png_read_grey(data)
+    elif codec == SIDE_FIXED:
+        out = _unpack_fixed(data, n, nbits)
+    else:
+        raw = lzma.decompress(data) if codec == SIDE_LZMA else data
+        if codec not in (SIDE_RAW, SIDE_LZMA):
+            raise ValueError(f"unknown side-string codec {codec}")
+        out = np.frombuffer(raw, np.uint8 if len(raw) == n else np.int16)
+    out = np.asarray(out).reshape(h, w).astype(np.int64)
+    return out
+
+
+def write_archive(path, bitstream: bytes, indices, H: int, W: int, try_png=True) -> int:
+    """Writes one MPA1 file; returns its size in bytes."""
+    idx = torch.as_tensor(indices).detach().cpu()
+    h, w = idx.shape
+    codec, nbits, side = encode_side_string(idx, try_png)
+    blob = _ARCHIVE_HEAD.pack(ARCHIVE_MAGIC, 1, codec, H, W, h, w, nbits, len(side), len(bitstream)) + side + bytes(bitstream)
+    with open(path, "wb") as fp:
+        fp.write(blob)
+    return len(blob)
+
+
+def read_archive(path):
+    """-> (main string, indices int64 [h, w], H, W)."""
+    with open(path, "rb") as fp:
+        blob = fp.read()
+    if len(blob) < _ARCHIVE_HEAD.size:
+        raise ValueError("not an MPA1 archive: too short")
+    magic, version, codec, H, W, h, w, nbits, nside, nmain = _ARCHIVE_HEAD.unpack_from(blob)
+    if magic != ARCHIVE_MAGIC or version != 1:
+        raise ValueError("not an MPA1 archive (bad magic or version)")
+    o = _ARCHIVE_HEAD.size
+    if len(blob) != o + nside + nmain:
+        raise ValueError("MPA1 archive is truncated")
+    side, main = blob[o:o + nside], blob[o + nside:]
+    return main, torch.from_numpy(decode_side_string(codec, nbits, side, h, w)), H, W

@@ -49,3 +49,26 @@ def test_product_package_does_not_import_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src, f
+
+
+def test_archive_container_round_trip(tmp_path):
+    """MPA1: main string + cheapest side-string coding in one file; its side string costs what get_num_bits says."""
+    import numpy as np
+    import torch
+    from compression_amd import pt_helpers
+    rng = np.random.default_rng(3)
+    for h, w, hi in ((32, 48, 64), (4, 6, 3), (8, 8, 1), (16, 24, 300)):
+        idx = torch.from_numpy(rng.integers(0, hi, size=(h, w)))
+        if hi == 1:
+            idx[:] = 0
+        main = rng.integers(0, 256, size=1000, dtype=np.uint8).tobytes()
+        p = tmp_path / f"a{h}.mpa"
+        n = pt_helpers.write_archive(str(p), main, idx, 16 * h, 16 * w)
+        m2, idx2, H, W = pt_helpers.read_archive(str(p))
+        assert m2 == main and torch.equal(idx2, idx.to(torch.int64)) and (H, W) == (16 * h, 16 * w)
+        side_bits = pt_helpers.get_num_bits(idx.view(1, h, w), integers=True, try_png=True)
+        assert 8 * (n - pt_helpers._ARCHIVE_HEAD.size - len(main)) == (side_bits + 7) // 8 * 8
+    (tmp_path / "bad").write_bytes(b"MPA1" + b"\0" * 10)
+    import pytest
+    with pytest.raises(ValueError):
+        pt_helpers.read_archive(str(tmp_path / "bad"))

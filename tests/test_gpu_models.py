@@ -271,6 +271,16 @@ def _lib_error():
     return (MpcError, ValueError)
 
 
+def test_single_file_archive(model, dev, tmp_path):
+    """encode_to_archive / decode_archive: one file holds the main string, the prior-index map and the sizes."""
+    x = synth.smooth_image(12, 1, 128, 192).to(dev)
+    path = str(tmp_path / "img.mpa")
+    nbytes = model.encode_to_archive(x, path)
+    bitstream, indices, h, w = model.encode(x)
+    assert nbytes > len(bitstream) and nbytes < len(bitstream) + 200
+    assert torch.equal(model.decode_archive(path), model.decode([bitstream, indices, h, w]))
+
+
 def test_image_metrics_on_device(dev, golden):
     """Device SSIM / MS-SSIM / PSNR (the statistics test_dir accumulates) against the reference capture; fp32
     filtering in another summation order, so to 1e-5, not to the bit."""
