@@ -72,3 +72,41 @@ def test_archive_container_round_trip(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         pt_helpers.read_archive(str(tmp_path / "bad"))
+
+
+def test_stream_geometry_invariants():
+    """choose_streams: every location is covered, the 16-bit stream-length field is respected, the header overhead
+    stays within the budget unless the length field forces more streams, and empty streams are dropped."""
+    from compression_amd import ops
+    for n_loc, M, est in ((1536, 256, 172e3), (96, 256, 8e3), (31680, 256, 3.5e6), (6, 192, 400.0), (1, 256, 50.0),
+                          (1536, 320, 10.0), (4096, 8, 1e4)):
+        n, lps = ops.choose_streams(n_loc, M, est)
+        assert n >= 1 and lps >= 1 and n * lps >= n_loc and (n - 1) * lps < n_loc
+        assert lps * M + 2 <= 65535
+        min_streams = -(-n_loc // max(1, ops.MRS1_MAX_SYMBOLS_PER_STREAM // M))
+        if n > min_streams:
+            assert ops.MRS1_FIXED_HEADER + n * ops.MRS1_STREAM_OVERHEAD <= est * 0.004 + ops.MRS1_STREAM_OVERHEAD
+
+
+def test_statistics_accumulator_with_msssim():
+    import math
+    from compression_amd.distributed import StatsAccumulator
+    acc = StatsAccumulator()
+    acc.add_image(bits=8000, pixels=100 * 100, sq_err=3.0, nbytes=1000, msssim=0.99)
+    acc.add_image(bits=4000, pixels=100 * 100, sq_err=6.0, nbytes=500, msssim=0.9)
+    r = acc.all_reduce().result()
+    assert r["images"] == 2 and r["bpp"] == 12000 / 20000
+    assert r["msssim"] == (0.99 + 0.9) / 2
+    assert abs(r["msssimDB"] - (-10 * math.log10(0.01) - 10 * math.log10(0.1)) / 2) < 1e-9
+    assert abs(r["psnr"] - (10 * math.log10(30000 / 3.0) + 10 * math.log10(30000 / 6.0)) / 2) < 1e-9
+
+
+def test_hyperprior_latent_sizes_and_window():
+    """Host arithmetic of the hyperprior codec and of the statistics module (no kernel is called)."""
+    import torch
+    from compression_amd import pt_ms_ssim
+    from compression_amd.abstract_model import AbstractHyperpriorImageCompressor as A
+    assert A._latent_hw(None, 128, 192) == ((8, 12), (2, 3))
+    assert A._latent_hw(None, 512, 768) == ((32, 48), (8, 12))
+    from oracle import manypriors_oracle as O
+    assert torch.equal(pt_ms_ssim._fspecial_gauss_1d(11, 1.5), O.gauss_window(11, 1.5))
