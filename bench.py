@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Manypriors codec inference path on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the encode+decode metric is quoted on): the full codec
+Workload (the configuration the encode+decode metric is quoted on): the full codec
 on a batch of 24 synthetic Kodak-shaped 768x512 images per GPU with the standard model (N=192, M=256, K=64,
 random-init transforms, spread priors): one STEP =
     encode:  g_a -> round -> symbols -> prior competition -> MRS1 rANS -> byte strings on the host
