@@ -11,10 +11,13 @@
  *   - all `*_dev` / unmarked data pointers are DEVICE pointers on the context's GPU unless the
  *     parameter is documented as host memory; the caller owns every buffer it passes;
  *   - work is enqueued on the context's HIP stream and is asynchronous unless stated otherwise;
- *   - a context is not thread-safe; distinct contexts may be used from distinct threads.
+ *   - a context is not thread-safe; distinct contexts may be used from distinct threads;
+ *   - a context owns one device scratch buffer that grows on demand (the decoder's copy of the CDF table
+ *     with aligned rows); calls on one context must therefore not overlap in time on different streams.
  *
- * Activations are NHWC fp32 inside the library ([B][H][W][C], C contiguous).  The quantised latent
- * in that layout IS the reference's symbol order (location-major, channel-minor,
+ * Activations are NHWC ([B][H][W][C], C contiguous): fp32 on the exact path, fp16 between MPC_F16 layers, the
+ * split format described at MPC_F16X3 between split-precision layers.  The quantised latent in NHWC IS the
+ * reference's symbol order (location-major, channel-minor,
  * src/compression/models/manynets_compressor.py:264-269).
  */
 #ifndef MPC_H
@@ -138,7 +141,9 @@ int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
 /* Decodes n_images containers (in + i*in_stride, nbytes_dev[i] bytes; nbytes_dev is a device array)
  * into sym_out + i*n_loc*M.  n_streams / locs_per_stream are the values the containers were written
  * with (fields 1 and 3 of the header; every image of the batch must share them).  status_dev[i]
- * (device int32) is 0 or a negative detail code of MPC_EDATA. */
+ * (device int32) is 0 or a negative detail code of MPC_EDATA.  Tables with L = 257 (256-symbol rows, the standard
+ * model) take the fast path: rows streamed into LDS by a loader wave, searched by a decoder wave; it works on a
+ * copy of the table with 16-byte aligned rows made by this call in the context's scratch (K*M*528 bytes). */
 int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                     const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
                     int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
