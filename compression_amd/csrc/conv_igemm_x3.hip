@@ -101,8 +101,13 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
                 dst[2 * ks + 1] = __builtin_bit_cast(float4, vl);
             }
         } else {
+#ifdef MPC_X3_K_BLOCK_MAJOR
+            int cb = chunk / ph.ntaps;                     // K walked as (channel block, tap): see wseq below
+            int tap = chunk - cb * ph.ntaps;
+#else
             int tap = chunk / p.cin_blocks;
             int cb = chunk - tap * p.cin_blocks;
+#endif
             int2 d = taps[tap];
             int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
             bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
@@ -135,6 +140,20 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
         for (int r = 0; r < STAGE; ++r) d[r * NT] = src[r];
     };
 
+    // Position in the packed weights of the c-th chunk of the K loop.  The weights are packed tap-major
+    // (chunk = tap * channel blocks + block), which is also the default walk.  Built with
+    // -DMPC_X3_K_BLOCK_MAJOR the loop walks (channel block, tap) instead: one pass over the taps of a 32-channel
+    // block re-reads a six times smaller set of input bytes (an L2-sized one at the benchmark's shapes); only the
+    // summation order changes.  Not the default until it has been measured.
+    auto wseq = [&](int c) -> int64_t {
+#ifdef MPC_X3_K_BLOCK_MAJOR
+        if constexpr (!RGB) {
+            const int cb = c / ph.ntaps;
+            return (int64_t)(c - cb * ph.ntaps) * p.cin_blocks + cb;
+        }
+#endif
+        return c;
+    };
     f32x16 acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
     for (int ch = 0; ch < nch; ++ch) {
         // unconditional prefetch (keeps everything in registers); after the last chunk: the first gamma chunk
         const int nxt = (ch + 1 < nch) ? ch + 1 : ch;
-        load_w((ch + 1 < nch || !gdn_mix16) ? wsrc + (int64_t)nxt * CHUNK_F4 : gsrc, wreg);
+        load_w((ch + 1 < nch || !gdn_mix16) ? wsrc + wseq(nxt) * CHUNK_F4 : gsrc, wreg);
         load_b(nxt, bnext);
         // slot index ((ks*2 + h)*2 + part)*COUT + cout
         const float4 *wl = lds + (ch & 1) * CHUNK_F4 + (h * 2) * COUT + j;
