@@ -11,7 +11,8 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpc.so")
+# MPC_LIB selects another build of the same library (A/B measurements of experimental builds)
+LIB_PATH = os.environ.get("MPC_LIB") or os.path.join(_HERE, "libmpc.so")
 
 MPC_ORDER_ROUND_THEN_ADD = 0
 MPC_ORDER_ADD_THEN_ROUND = 1

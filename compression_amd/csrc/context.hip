@@ -2,6 +2,8 @@
 #include "mpc_internal.h"
 
 void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes) {
+    if (ctx->scratch_done && ctx->scratch_stream != ctx->stream)
+        (void)hipStreamWaitEvent(ctx->stream, ctx->scratch_done, 0);
     if (bytes <= ctx->scratch_bytes) return ctx->scratch;
     (void)hipFree(ctx->scratch);                // synchronises with work still using the old buffer
     ctx->scratch = nullptr;
@@ -16,16 +18,26 @@ void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes) {
     return ctx->scratch;
 }
 
+void mpc_ctx_scratch_release(mpc_ctx *ctx) {
+    if (!ctx->scratch_done && hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming) != hipSuccess) {
+        ctx->scratch_done = nullptr;
+        return;
+    }
+    (void)hipEventRecord(ctx->scratch_done, ctx->stream);
+    ctx->scratch_stream = ctx->stream;
+}
+
 extern "C" {
 
-const char *mpc_version(void) { return "libmpc 0.1 gfx950 (hand-written HIP, f32 MFMA transforms, MRS1 rANS)"; }
+const char *mpc_version(void) { return "libmpc 0.2 gfx950 (hand-written HIP: f32 / split-fp16 / fp16 MFMA transforms, prior competition, MRS1 rANS)"; }
 
 int mpc_create(int device_id, void *stream, mpc_ctx **out) {
     if (!out) return MPC_EINVAL;
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return MPC_EHIP;
-    if (hipSetDevice(device_id) != hipSuccess) return MPC_EHIP;
+    mpc_device_guard guard(device_id);          // the caller's current device is put back on return
+    if (hipFree(nullptr) != hipSuccess) return MPC_EHIP;
     mpc_ctx *c = new mpc_ctx();
     c->device = device_id;
     c->stream = (hipStream_t)stream;
@@ -35,18 +47,24 @@ int mpc_create(int device_id, void *stream, mpc_ctx **out) {
 }
 
 int mpc_destroy(mpc_ctx *ctx) {
-    if (ctx) (void)hipFree(ctx->scratch);
+    if (ctx) {
+        mpc_device_guard guard(ctx->device);
+        (void)hipFree(ctx->scratch);
+        if (ctx->scratch_done) (void)hipEventDestroy(ctx->scratch_done);
+    }
     delete ctx;
     return MPC_OK;
 }
 
 int mpc_set_stream(mpc_ctx *ctx, void *stream) {
+    MPC_ENTER(ctx);
     if (!ctx) return MPC_EINVAL;
     ctx->stream = (hipStream_t)stream;
     return MPC_OK;
 }
 
 int mpc_synchronize(mpc_ctx *ctx) {
+    MPC_ENTER(ctx);
     if (!ctx) return MPC_EINVAL;
     MPC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MPC_OK;
@@ -172,6 +190,7 @@ __global__ void f16_to_f32_kernel(const _Float16 *__restrict__ in, int64_t n, fl
 extern "C" {
 
 int mpc_f32_to_f16(mpc_ctx *ctx, const float *in, int64_t n, void *out_f16) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in && out_f16 && n > 0, "f32_to_f16: bad arguments");
     f32_to_f16_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(in, n, (_Float16 *)out_f16);
     MPC_CHECK_LAUNCH(ctx, "f32_to_f16");
@@ -179,6 +198,7 @@ int mpc_f32_to_f16(mpc_ctx *ctx, const float *in, int64_t n, void *out_f16) {
 }
 
 int mpc_f16_to_f32(mpc_ctx *ctx, const void *in_f16, int64_t n, float *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in_f16 && out && n > 0, "f16_to_f32: bad arguments");
     f16_to_f32_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>((const _Float16 *)in_f16, n, out);
     MPC_CHECK_LAUNCH(ctx, "f16_to_f32");
@@ -186,6 +206,7 @@ int mpc_f16_to_f32(mpc_ctx *ctx, const void *in_f16, int64_t n, float *out) {
 }
 
 int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat, double *sse_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, recon && n > 0 && (xhat || (sse_dev && target)), "clamp_sse: bad arguments");
     if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double), ctx->stream));
     int64_t blocks = mpc_cdiv(n, 256 * 4);
@@ -197,6 +218,7 @@ int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t
 }
 
 int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, int Cpad, float *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad arguments");
     int64_t total = (int64_t)B * H * W * Cpad;
     nchw_to_nhwc_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(in, C, H * W, Cpad, total, out);
@@ -205,6 +227,7 @@ int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, 
 }
 
 int mpc_nhwc_to_nchw(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, float *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
     int64_t total = (int64_t)B * H * W * C;
     nhwc_to_nchw_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(in, C, H * W, total, out);
@@ -214,6 +237,7 @@ int mpc_nhwc_to_nchw(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, 
 
 int mpc_latent_to_symbols(mpc_ctx *ctx, const float *latent, int64_t n, int min_feat, int q_intv,
                           int n_sym_values, int16_t *sym, int32_t *n_clamped_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, latent && sym && n > 0 && q_intv > 0 && n_sym_values > 0 && n_sym_values <= 32767,
                 "latent_to_symbols: bad arguments");
     if (n_clamped_dev) MPC_HIP(ctx, hipMemsetAsync(n_clamped_dev, 0, sizeof(int32_t), ctx->stream));
@@ -224,6 +248,7 @@ int mpc_latent_to_symbols(mpc_ctx *ctx, const float *latent, int64_t n, int min_
 }
 
 int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_feat, int q_intv, float *latent) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, latent && sym && n > 0, "symbols_to_latent: bad arguments");
     symbols_to_latent_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(sym, n, min_feat, q_intv, latent);
     MPC_CHECK_LAUNCH(ctx, "symbols_to_latent");
@@ -231,6 +256,7 @@ int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_f
 }
 
 int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, x && out_dev && n > 0, "sum_f32: bad arguments");
     MPC_HIP(ctx, hipMemsetAsync(out_dev, 0, sizeof(double), ctx->stream));
     int64_t blocks = mpc_cdiv(n, 256 * 8);

@@ -461,10 +461,11 @@ template <int NF, bool CIN4, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
     size_t lds = (size_t)2 * NF * 32 * 32 * sizeof(float);
     auto kern = conv_igemm_kernel<NF, CIN4, EPI>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static bool attr_set[MPC_MAX_DEVICES] = {};        // per device (the attribute lives in the device's code object)
+    bool &attr_done = attr_set[ctx->device];
+    if (lds > 48 * 1024 && !attr_done) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_done = true;
     }
     int64_t bx = xcd_grid(mpc_cdiv(p.P, PIX_PER_BLOCK));
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");
@@ -479,6 +480,7 @@ extern "C" {
 
 int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight, const float *bias,
                     const float *beta, const float *gamma, mpc_conv **out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, desc && weight && bias && out, "conv_create: NULL argument");
     const mpc_conv_desc &d = *desc;
     const bool gdn = d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN;
@@ -513,9 +515,10 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     MPC_REQUIRE(ctx, !gdn || groups == 1, "conv_create: fused GDN supports cout <= 192");
     MPC_REQUIRE(ctx, !(stacked && (gdn || d.act != MPC_ACT_NONE)), "conv_create: small-cout layer supports no activation");
 
+    MPC_REQUIRE(ctx, !f16 || groups == 1, "conv_create: the fp16 path supports cout <= 192");
+
     mpc_conv *c = new mpc_conv();
     c->desc = d; c->device = ctx->device; c->nf = nf; c->groups = groups; c->cin4 = cin4; c->stacked = stacked; c->f16 = f16; c->x3 = x3;
-    MPC_REQUIRE(ctx, !f16 || groups == 1, "conv_create: the fp16 path supports cout <= 192");
 
     PackDesc pd;
     memset(&pd, 0, sizeof(pd));
@@ -660,6 +663,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
 
 int mpc_conv_destroy(mpc_conv *c) {
     if (!c) return MPC_OK;
+    mpc_device_guard guard(c->device);
     (void)hipFree(c->wpk); (void)hipFree(c->bias); (void)hipFree(c->beta); (void)hipFree(c->gamma); (void)hipFree(c->taps);
     (void)hipFree(c->gamma_x3);
     (void)hipFree(c->wpk_rgb16);
@@ -682,6 +686,7 @@ int mpc_conv_out_hw(const mpc_conv *c, int H, int W, int *Ho, int *Wo) {
 
 int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
                      float *out_round) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, c && in && B > 0 && H > 0 && W > 0, "conv_forward: bad arguments");
     MPC_REQUIRE(ctx, c->device == ctx->device, "conv_forward: layer was created on another device");
     const mpc_conv_desc &d = c->desc;

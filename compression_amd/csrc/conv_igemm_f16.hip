@@ -228,10 +228,11 @@ int launch_nw(mpc_ctx *ctx, const Params &p, int nphase) {
     size_t lds = (size_t)2 * NF * 32 * 8 * sizeof(float4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
     auto kern = conv_igemm_f16_kernel<NF, EPI, NW>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static bool attr_set[MPC_MAX_DEVICES] = {};        // per device (the attribute lives in the device's code object)
+    bool &attr_done = attr_set[ctx->device];
+    if (lds > 48 * 1024 && !attr_done) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_done = true;
     }
     int64_t bx = xcd_grid(mpc_cdiv(p.P, 32 * NW));
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many pixels");

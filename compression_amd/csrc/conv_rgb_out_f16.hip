@@ -256,10 +256,11 @@ hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *ima
 int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     const int nsteps = 9 * (c->desc.cin / 64);
     const size_t lds = mpc_conv_rgb16_image_bytes(c->desc.cin);
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
+    static bool attr_set[MPC_MAX_DEVICES] = {};        // per device (the attribute lives in the device's code object)
+    bool &attr_done = attr_set[ctx->device];
+    if (lds > 48 * 1024 && !attr_done) {
         MPC_HIP(ctx, hipFuncSetAttribute((const void *)deconv_rgb16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_done = true;
     }
     if (p.Wb % ROWS_TILE == 0 && p.Hb == p.Hi && p.Wb == p.Wi) {
         const size_t lds_rows = lds + (size_t)ROWS_WAVES * ROWS_STAGE_F4 * sizeof(float4);

@@ -178,6 +178,7 @@ extern "C" {
 
 int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n_rows, float first_target,
                           int L, float *table_f) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, params && table_f && n_rows > 0 && L > 1, "bitparm_cdf_table: bad arguments");
     float *prep = nullptr;
     int rc = make_prep(ctx, params, n_rows, &prep);
@@ -190,6 +191,7 @@ int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n
 
 int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_rows, const float *x,
                          int64_t n_per_row, int row_minor, float offset, float *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, params && x && out && n_rows > 0 && n_per_row > 0, "bitparm_cdf_eval: bad arguments");
     float *prep = nullptr;
     int rc = make_prep(ctx, params, n_rows, &prep);
@@ -202,6 +204,7 @@ int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_
 
 int mpc_renorm_cast_cdf(mpc_ctx *ctx, const float *cdf, int64_t n_rows, int L, int precision, int order,
                         int16_t *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, cdf && out && n_rows > 0 && L > 1 && precision >= 8 && precision <= 16 &&
                          (order == MPC_ORDER_ROUND_THEN_ADD || order == MPC_ORDER_ADD_THEN_ROUND),
                 "renorm_cast_cdf: bad arguments");
@@ -212,6 +215,7 @@ int mpc_renorm_cast_cdf(mpc_ctx *ctx, const float *cdf, int64_t n_rows, int L, i
 }
 
 int mpc_bits_lut(mpc_ctx *ctx, const float *table_f, int K, int M, int L, int form, float *lut) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, table_f && lut && K > 0 && M > 0 && L > 1 && (form == MPC_BITS_LOG2 || form == MPC_BITS_LN),
                 "bits_lut: bad arguments");
     bits_lut_kernel<<<dim3(blocks_for((int64_t)M * (L - 1) * K)), dim3(256), 0, ctx->stream>>>(table_f, K, M, L, form, lut);
@@ -220,6 +224,7 @@ int mpc_bits_lut(mpc_ctx *ctx, const float *table_f, int K, int M, int L, int fo
 }
 
 int mpc_laplace_bits(mpc_ctx *ctx, const float *yhat, const float *sigma, int64_t n, float *bits, double *total_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, yhat && sigma && n > 0 && (bits || total_dev), "laplace_bits: bad arguments");
     laplace_bits_kernel<<<dim3(blocks_for(n)), dim3(256), 0, ctx->stream>>>(yhat, sigma, n, bits, total_dev);
     MPC_CHECK_LAUNCH(ctx, "laplace_bits");
@@ -227,6 +232,7 @@ int mpc_laplace_bits(mpc_ctx *ctx, const float *yhat, const float *sigma, int64_
 }
 
 int mpc_prob_bits(mpc_ctx *ctx, const float *cdf_hi, const float *cdf_lo, int64_t n, float *bits, double *total_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, cdf_hi && cdf_lo && n > 0 && (bits || total_dev), "prob_bits: bad arguments");
     prob_bits_kernel<<<dim3(blocks_for(n)), dim3(256), 0, ctx->stream>>>(cdf_hi, cdf_lo, n, bits, total_dev);
     MPC_CHECK_LAUNCH(ctx, "prob_bits");
@@ -235,6 +241,7 @@ int mpc_prob_bits(mpc_ctx *ctx, const float *cdf_hi, const float *cdf_lo, int64_
 
 int mpc_laplace_cdf_rows(mpc_ctx *ctx, const float *sigma, int64_t n, float first_target, int L, int precision,
                          int16_t *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, sigma && out && n > 0 && L > 1 && precision >= 8 && precision <= 16, "laplace_cdf_rows: bad arguments");
     float factor = (float)(1 << precision) - (float)(L - 1);
     laplace_rows_kernel<<<dim3(blocks_for(n * L)), dim3(256), 0, ctx->stream>>>(sigma, n, first_target, L, factor, out);

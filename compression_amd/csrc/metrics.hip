@@ -107,6 +107,7 @@ extern "C" {
 
 int mpc_ssim_stats(mpc_ctx *ctx, const float *x, const float *y, int planes, int H, int W, const float *window,
                    int win_size, float C1, float C2, double *ssim_sum_dev, double *cs_sum_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, x && y && window && ssim_sum_dev && cs_sum_dev && planes > 0, "ssim_stats: bad arguments");
     MPC_REQUIRE(ctx, win_size >= 1 && win_size <= MAX_WIN && (win_size & 1), "ssim_stats: window size must be odd and <= 15");
     MPC_REQUIRE(ctx, H >= win_size && W >= win_size, "ssim_stats: image smaller than the window");
@@ -129,6 +130,7 @@ int mpc_ssim_stats(mpc_ctx *ctx, const float *x, const float *y, int planes, int
 }
 
 int mpc_avg_pool2(mpc_ctx *ctx, const float *in, int64_t planes, int H, int W, float *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in && out && planes > 0 && H > 0 && W > 0, "avg_pool2: bad arguments");
     const int ph = H % 2, pw = W % 2;
     const int Ho = (H + 2 * ph - 2) / 2 + 1, Wo = (W + 2 * pw - 2) / 2 + 1;

@@ -13,11 +13,16 @@ struct mpc_ctx {
     char err[512];
     void *scratch = nullptr;      // library-owned device scratch, grown on demand (mpc_ctx_scratch)
     size_t scratch_bytes = 0;
+    hipEvent_t scratch_done = nullptr;     // recorded after the last kernel that used the scratch ...
+    hipStream_t scratch_stream = nullptr;  // ... on this stream
 };
 
 // Device scratch of at least `bytes` owned by the context (contents undefined; valid until the next call
-// that asks for more).  Returns nullptr and sets the context's error text on failure.
+// that asks for more).  Returns nullptr and sets the context's error text on failure.  If the previous user ran on
+// another stream, the context's current stream is made to wait for it first.  The caller enqueues its kernels on
+// ctx->stream and then calls mpc_ctx_scratch_release.
 void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes);
+void mpc_ctx_scratch_release(mpc_ctx *ctx);
 
 #define MPC_FAIL(ctx, code, ...)                                   \
     do {                                                           \
@@ -44,5 +49,25 @@ void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes);
     do {                                                 \
         if (!(cond)) MPC_FAIL(ctx, MPC_EINVAL, __VA_ARGS__); \
     } while (0)
+
+// Every entry point that takes a context runs with the context's device current and puts the caller's device
+// back on return, so a process may hold contexts on several GPUs (and torch's current device is left alone).
+struct mpc_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit mpc_device_guard(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+    }
+    ~mpc_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    mpc_device_guard(const mpc_device_guard &) = delete;
+    mpc_device_guard &operator=(const mpc_device_guard &) = delete;
+};
+#define MPC_ENTER(ctx)                  \
+    if (!(ctx)) return MPC_EINVAL;      \
+    mpc_device_guard mpc_guard__((ctx)->device)
+
+constexpr int MPC_MAX_DEVICES = 64;     // per-device flags (kernel attributes set, static scratch addresses)
 
 static inline int64_t mpc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -144,6 +144,7 @@ extern "C" {
 
 int mpc_prior_argmin(mpc_ctx *ctx, const int16_t *sym, int64_t n_loc, int M, int K, int S, const float *lut,
                      int32_t *idx, float *minbits, float *total_bits) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, sym && lut && idx && minbits && n_loc > 0 && M > 0 && M < 4096 && K > 0 && K <= 64 && S > 0,
                 "prior_argmin: bad arguments (need 0 < K <= 64, 0 < M < 4096)");
     int64_t blocks = mpc_cdiv(n_loc, WAVES_PER_BLOCK);
@@ -155,6 +156,7 @@ int mpc_prior_argmin(mpc_ctx *ctx, const int16_t *sym, int64_t n_loc, int M, int
 
 int mpc_gather_cdf(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, int64_t n_loc,
                    int16_t *out) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, table && idx && out && K > 0 && M > 0 && L > 1 && n_loc > 0 && n_loc < (1ll << 31),
                 "gather_cdf: bad arguments");
     int64_t per_prior = (int64_t)M * L;

@@ -220,10 +220,10 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
     const uint32_t stream = (uint32_t)(gid % g.n_streams);
     const uint8_t *src = in + (size_t)img * in_stride;
     const uint64_t nb = nbytes[img];
-    const uint32_t hdr = 16 + 2 * (uint32_t)g.n_streams;
+    const uint64_t hdr = 16 + 2 * (uint64_t)g.n_streams;   // the host has checked hdr <= in_stride < 2^32
     int err = 0;
-    if (nb < hdr) err = -20;
-    uint32_t my_len = 0, off = hdr;
+    if (nb < hdr || nb > in_stride) err = -20;
+    uint32_t my_len = 0, off = (uint32_t)hdr;
     if (!err) {
         const uint32_t *h4 = (const uint32_t *)src;
         if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
@@ -368,9 +368,9 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
         const uint32_t stream = live ? (uint32_t)(gid % g.n_streams) : 0;
         const uint8_t *src = in + (size_t)img * in_stride;
         const uint64_t nb = nbytes[img];
-        const uint32_t hdr = 16 + 2 * (uint32_t)g.n_streams;
-        if (nb < hdr) err = -20;
-        uint32_t off = hdr;
+        const uint64_t hdr = 16 + 2 * (uint64_t)g.n_streams;   // the host has checked hdr <= in_stride < 2^32
+        if (nb < hdr || nb > in_stride) err = -20;
+        uint32_t off = (uint32_t)hdr;
         if (!err) {
             const uint32_t *h4 = (const uint32_t *)src;
             if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
@@ -585,6 +585,7 @@ int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
                     int n_images, int64_t n_loc, int n_streams, int locs_per_stream, void *workspace,
                     size_t workspace_bytes, uint8_t *out, size_t out_stride, uint64_t *nbytes_dev,
                     int32_t *status_dev) {
+    MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, table && idx && sym && workspace && out && nbytes_dev && status_dev, "rans_encode: NULL argument");
     Geometry g;
     int rc = check_geometry(ctx, g, K, M, L, n_images, n_loc, n_streams, locs_per_stream);
@@ -611,32 +612,60 @@ int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     return MPC_OK;
 }
 
-int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const uint8_t *in,
-                    size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int n_streams,
-                    int locs_per_stream, int16_t *sym_out, int32_t *status_dev) {
-    MPC_REQUIRE(ctx, table && idx && in && nbytes_dev && sym_out && status_dev, "rans_decode: NULL argument");
-    Geometry g;
-    int rc = check_geometry(ctx, g, K, M, L, n_images, n_loc, n_streams, locs_per_stream);
-    if (rc) return rc;
-    MPC_REQUIRE(ctx, ((uintptr_t)in % 4) == 0 && in_stride % 4 == 0, "rans_decode: in must be 4-byte aligned with a stride multiple of 4");
-    int64_t G = (int64_t)n_images * n_streams;
-    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * n_images, ctx->stream));
-    if (L == 257) {
+// Shared body of the two decode entry points.  `aligned_rows`: device buffer of K*M*DMA_PITCH uint16 for the
+// 16-byte aligned copy of the table (L == 257 only; unused otherwise).
+static int rans_decode_launch(mpc_ctx *ctx, const Geometry &g, const int16_t *table, const int32_t *idx, const uint8_t *in,
+                              size_t in_stride, const uint64_t *nbytes_dev, int16_t *sym_out, int32_t *status_dev,
+                              void *aligned_rows) {
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
+    if (g.L == 257) {
         // aligned copy of the table for the LDS-DMA row loads (rebuilt per call: the caller may have changed the table)
-        const int64_t rows = (int64_t)K * M;
-        void *aligned = mpc_ctx_scratch(ctx, (size_t)rows * DMA_PITCH * sizeof(uint16_t));
-        if (!aligned) return MPC_EHIP;
+        const int64_t rows = (int64_t)g.K * g.M;
         align_rows_kernel<<<dim3((unsigned)mpc_cdiv(rows * DMA_PITCH, 256)), dim3(256), 0, ctx->stream>>>(
-            (const uint16_t *)table, rows, L, (uint16_t *)aligned);
+            (const uint16_t *)table, rows, g.L, (uint16_t *)aligned_rows);
         MPC_CHECK_LAUNCH(ctx, "rans align_rows");
         decode_streams_dma_kernel<<<dim3((unsigned)mpc_cdiv(G, 4)), dim3(128), 0, ctx->stream>>>(
-            g, (const uint16_t *)aligned, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+            g, (const uint16_t *)aligned_rows, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
     } else {
         decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
             g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
     }
     MPC_CHECK_LAUNCH(ctx, "rans decode_streams");
     return MPC_OK;
+}
+
+static int rans_decode_check(mpc_ctx *ctx, Geometry &g, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                             const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc,
+                             int n_streams, int locs_per_stream, int16_t *sym_out, int32_t *status_dev) {
+    MPC_REQUIRE(ctx, table && idx && in && nbytes_dev && sym_out && status_dev, "rans_decode: NULL argument");
+    int rc = check_geometry(ctx, g, K, M, L, n_images, n_loc, n_streams, locs_per_stream);
+    if (rc) return rc;
+    MPC_REQUIRE(ctx, ((uintptr_t)in % 4) == 0 && in_stride % 4 == 0, "rans_decode: in must be 4-byte aligned with a stride multiple of 4");
+    // the stream geometry comes from an untrusted container header: a stream holds at least one location, and the
+    // header (16 bytes + one 16-bit length per stream) must lie inside one image's slot
+    MPC_REQUIRE(ctx, (int64_t)n_streams <= n_loc, "rans_decode: more streams than locations (corrupt header?)");
+    MPC_REQUIRE(ctx, in_stride < (1ull << 32) && 16 + 2 * (size_t)n_streams <= in_stride,
+                "rans_decode: in_stride smaller than the container header (or >= 4 GiB)");
+    return MPC_OK;
+}
+
+int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const uint8_t *in,
+                    size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int n_streams,
+                    int locs_per_stream, int16_t *sym_out, int32_t *status_dev) {
+    MPC_ENTER(ctx);
+    Geometry g;
+    int rc = rans_decode_check(ctx, g, table, K, M, L, idx, in, in_stride, nbytes_dev, n_images, n_loc, n_streams,
+                               locs_per_stream, sym_out, status_dev);
+    if (rc) return rc;
+    void *aligned = nullptr;
+    if (L == 257) {
+        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * DMA_PITCH * sizeof(uint16_t));
+        if (!aligned) return MPC_EHIP;
+    }
+    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+    if (L == 257) mpc_ctx_scratch_release(ctx);
+    return rc;
 }
 
 }  // extern "C"

@@ -245,10 +245,9 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         self._ensure_tables()
         B, M = len(streams), self.out_channel_M
         dev = self.entropy_table.device
-        heads = [np.frombuffer(s[:16], dtype="<u4") for s in streams]
-        n_streams, sps = int(heads[0][1]), int(heads[0][3])
-        if any(int(hd[1]) != n_streams or int(hd[3]) != sps for hd in heads):
-            raise ValueError("decode_batch: all streams of a batch must share one stream geometry")
+        if idx.numel() != B * h * w:
+            raise ValueError(f"decode_batch: {idx.numel()} prior indices for {B} images of {h}x{w} locations")
+        n_streams, lps = ops.parse_mrs1_headers(streams, h * w, M)
         stride = (max(len(s) for s in streams) + 3) // 4 * 4
         stage = self._staging(B * stride)[:B * stride].view(B, stride)   # bytes past a stream's end are never read
         host = stage.numpy()
@@ -257,7 +256,7 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         data = stage.to(dev, non_blocking=True)
         nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64).to(dev, non_blocking=True)
         idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
-        sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, sps // M)
+        sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, lps)
         if int(status.min().item()) < 0:
             raise _lib.MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
         yhat = ops.symbols_to_latent(sym.view(B, h, w, M), self.min_feat, self.q_intv)

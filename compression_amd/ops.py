@@ -323,16 +323,43 @@ def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tens
     return [host[i, :nb[i]].tobytes() for i in range(n_images)]
 
 
+def parse_mrs1_headers(streams: Sequence[bytes], n_loc: int, M: int) -> Tuple[int, int]:
+    """Validates the 16-byte headers of MRS1 containers that are to be decoded in one call and returns the shared
+    (n_streams, locs_per_stream).  The header of a file is untrusted input: everything the device kernels derive
+    addresses from is checked here (magic, 0 < n_streams <= n_loc, the symbol count of the image, a whole number
+    of locations per stream, the length table inside the container)."""
+    import numpy as np
+    geo = None
+    for i, s in enumerate(streams):
+        if len(s) < MRS1_FIXED_HEADER:
+            raise ValueError(f"MRS1 container {i}: {len(s)} bytes is shorter than the fixed header")
+        magic, n_streams, n_symbols, sps = (int(v) for v in np.frombuffer(s[:16], dtype="<u4"))
+        if magic != 0x3153524D:
+            raise ValueError(f"MRS1 container {i}: bad magic {magic:#x}")
+        if not 0 < n_streams <= n_loc:
+            raise ValueError(f"MRS1 container {i}: {n_streams} streams for {n_loc} locations")
+        if n_symbols != n_loc * M:
+            raise ValueError(f"MRS1 container {i}: holds {n_symbols} symbols, the image has {n_loc * M}")
+        if sps == 0 or sps % M or sps > MRS1_MAX_SYMBOLS_PER_STREAM or n_streams * sps < n_symbols:
+            raise ValueError(f"MRS1 container {i}: {sps} symbols per stream does not fit {n_streams} streams x {M} channels")
+        if len(s) < MRS1_FIXED_HEADER + 2 * n_streams:
+            raise ValueError(f"MRS1 container {i}: truncated inside the stream-length table")
+        if geo is None:
+            geo = (n_streams, sps // M)
+        elif geo != (n_streams, sps // M):
+            raise ValueError("all containers of one decode call must share one stream geometry")
+    if geo is None:
+        raise ValueError("no MRS1 container given")
+    return geo
+
+
 def rans_decode_from_bytes(table: torch.Tensor, idx: torch.Tensor, streams: List[bytes]) -> torch.Tensor:
     """Inverse of rans_encode_to_bytes: -> int16 symbols [n_images, n_loc*M].  The stream geometry is read from the
     containers' headers (all images of the call must share it)."""
     import numpy as np
     K, M, L = table.shape
     B = len(streams)
-    heads = [np.frombuffer(s[:16], dtype="<u4") for s in streams]
-    n_streams, sps = int(heads[0][1]), int(heads[0][3])
-    if any(len(s) < 16 for s in streams) or any(int(h[1]) != n_streams or int(h[3]) != sps for h in heads):
-        raise ValueError("rans_decode_from_bytes: truncated container or differing stream geometry")
+    n_streams, lps = parse_mrs1_headers(streams, idx.numel() // max(B, 1), M)
     stride = (max(len(s) for s in streams) + 3) // 4 * 4
     host = np.zeros((B, stride), np.uint8)
     for i, s in enumerate(streams):
@@ -340,7 +367,7 @@ def rans_decode_from_bytes(table: torch.Tensor, idx: torch.Tensor, streams: List
     dev = table.device
     data = torch.from_numpy(host).to(dev)
     nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64, device=dev)
-    sym, status = rans_decode(table, idx.reshape(-1), data, nbytes, B, n_streams, sps // M)
+    sym, status = rans_decode(table, idx.reshape(-1), data, nbytes, B, n_streams, lps)
     if int(status.min().item()) < 0:
         raise MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
     return sym

@@ -110,3 +110,27 @@ def test_hyperprior_latent_sizes_and_window():
     assert A._latent_hw(None, 512, 768) == ((32, 48), (8, 12))
     from oracle import manypriors_oracle as O
     assert torch.equal(pt_ms_ssim._fspecial_gauss_1d(11, 1.5), O.gauss_window(11, 1.5))
+
+
+def test_mrs1_header_validation_on_the_host():
+    """parse_mrs1_headers refuses everything the device kernels would derive a wrong address from."""
+    import struct
+    from compression_amd import ops
+    n_loc, M = 120, 256
+    good = struct.pack("<4I", 0x3153524D, 4, n_loc * M, 30 * M) + b"\0" * 64
+    assert ops.parse_mrs1_headers([good, good], n_loc, M) == (4, 30)
+
+    def forged(**kw):
+        f = dict(magic=0x3153524D, n_streams=4, n_symbols=n_loc * M, sps=30 * M, tail=64)
+        f.update(kw)
+        return struct.pack("<4I", f["magic"], f["n_streams"], f["n_symbols"], f["sps"]) + b"\0" * f["tail"]
+
+    for bad in (b"MRS1", forged(magic=1), forged(n_streams=0), forged(n_streams=2 ** 31 - 8), forged(n_streams=n_loc + 1),
+                forged(n_symbols=n_loc * M + 1), forged(sps=30 * M + 1), forged(sps=0), forged(sps=10 * M),
+                forged(sps=65536 // M * M + M), forged(n_streams=100, sps=2 * M, tail=8)):
+        with pytest.raises(ValueError):
+            ops.parse_mrs1_headers([bad], n_loc, M)
+    with pytest.raises(ValueError, match="share one stream geometry"):
+        ops.parse_mrs1_headers([good, forged(n_streams=5, sps=24 * M)], n_loc, M)
+    with pytest.raises(ValueError):
+        ops.parse_mrs1_headers([], n_loc, M)

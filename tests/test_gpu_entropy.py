@@ -200,6 +200,26 @@ def test_rans_decode_flags_corruption(dev, ops, coder_case):
     assert st.cpu()[0] < 0 or not torch.equal(dec.cpu(), sym[:1])
 
 
+def test_rans_decode_refuses_crafted_geometry(dev, ops, coder_case):
+    """A header can claim anything: a stream count that would wrap the 32-bit header size, or more bytes than the
+    buffer holds, must end in an error or a negative status, never in reads outside the buffer."""
+    from compression_amd import MpcError
+    table, idx, sym, n_loc = coder_case
+    out, nbytes, _ = ops.rans_encode(table.to(dev), idx[:1].reshape(-1).to(dev), sym[:1].reshape(-1).to(dev), 1, 4, 30)
+    args = (table.to(dev), idx[:1].reshape(-1).to(dev), out, nbytes, 1)
+    with pytest.raises(MpcError, match="more streams than locations"):
+        ops.rans_decode(*args, 2 ** 31 - 8, 30)
+    with pytest.raises(MpcError):
+        ops.rans_decode(*args, n_loc, 1 << 20)                   # stream longer than the 16-bit length field allows
+    lying = torch.full_like(nbytes, out.shape[1] + 4096)           # claims more bytes than one image's slot
+    _, st = ops.rans_decode(args[0], args[1], out, lying, 1, 4, 30)
+    assert st.cpu().tolist() == [-20]
+    streams = [out[0, :int(nbytes.cpu()[0])].cpu().numpy().tobytes()]
+    forged = bytearray(streams[0]); forged[4:8] = (2 ** 31 - 8).to_bytes(4, "little")
+    with pytest.raises(ValueError, match="streams for"):
+        ops.rans_decode_from_bytes(args[0], args[1], [bytes(forged)])
+
+
 def test_rans_rejects_bad_symbols(dev, ops, coder_case):
     table, idx, sym, n_loc = coder_case
     s = sym[:1].clone().reshape(-1)
