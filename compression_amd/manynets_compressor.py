@@ -144,6 +144,7 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         sym = self._symbols(yhat)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
         dist_select = idx.view(B, h, w)
+        self.last_dist_select = dist_select          # the prior index map of the last forward (int32 [B,h,w], on the GPU)
         idx_cpu = dist_select.cpu()
         used = np.unique(idx_cpu.numpy())
         self.dists_last_use[used] = 0

@@ -1,0 +1,269 @@
+"""The benchmark's configurations at their own sizes, in the benchmark's precision mix (split-fp16 analysis, fp16
+synthesis), against the CPU ORACLE (not against this package's own exact path):
+
+  config "full codec on 24 x 768x512"      -> test_kodak_batch_images_against_oracle
+  config "training shape 16 x 256x256"     -> test_training_shape_forward_against_oracle
+  config "3840x2160"  (135 latent rows)    -> test_4k_2160_against_oracle
+  config "JDC 1024x1024" (+ Testolina)     -> test_jdc_1024_codec_against_oracle, test_testolina_hyperprior_forward
+  the learned tables                       -> test_device_tables_against_reference_capture
+
+The oracle runs live on the host's CPU (seconds per case); a prior index may differ from the oracle's only where the
+oracle's own totals put both candidates within fp32 rounding of each other, and a symbol only where the oracle's
+latent sits on a rounding tie.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coders, manypriors_oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+N, M, K = 192, 256, 64
+TIE_BITS = 2e-3          # two totals (sums of 256 terms of up to 50 bits, ~1e3 bits) closer than this are a tie in fp32
+TIE_LATENT = 1e-4        # a latent closer than this to k + 0.5 may round either way
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.manypriors_state_dict(234, N, M, K, spread=True)
+
+
+@pytest.fixture(scope="module")
+def table_f(sd):
+    return O.entropy_table_float(sd, M).contiguous()
+
+
+@pytest.fixture(scope="module")
+def fast(dev, sd):
+    """The benchmark's model: f16x3 analysis, fp16 synthesis."""
+    import compression_amd as ca
+    from compression_amd import manynets_compressor
+    manynets_compressor.TRY_PNG_SIDESTRING = False
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K,
+                      analysis_precision="f16x3", synthesis_precision="fp16")
+    m.load_state_dict(sd)
+    return m.eval()
+
+
+def check_symbols(y_ref, sym_dev, what):
+    """sym_dev (location-major, channel-minor, images in order) against round(y_ref [B,M,h,w]); flips only on rounding
+    ties, at most 1e-5 of the symbols.  Returns the set of (batch-global) locations that hold a flipped symbol."""
+    B, Mc = y_ref.shape[:2]
+    want = O.symbols_from_latent(torch.round(y_ref)).reshape(-1)
+    got = sym_dev.reshape(-1).cpu()
+    flips = (want != got).nonzero().reshape(-1)
+    yflat = y_ref.reshape(B, Mc, -1).transpose(1, 2).reshape(-1)
+    tie = (yflat[flips] - torch.floor(yflat[flips]) - 0.5).abs()
+    print(f"{what}: {flips.numel()} / {got.numel()} symbols differ from the oracle" +
+          (f" (farthest from a rounding tie: {float(tie.max()):.1e})" if flips.numel() else ""))
+    assert flips.numel() <= max(1, int(1e-5 * got.numel()))
+    assert flips.numel() == 0 or float(tie.max()) < TIE_LATENT
+    return set((flips // Mc).tolist())
+
+
+def _latent(yhat_ref, sym_dev, bad):
+    """The latent g_s is checked on: the oracle's own, or -- when a rounding tie made a symbol differ -- the device's
+    symbols turned back into a latent (x_hat is then the oracle's synthesis of the same quantised latent)."""
+    if not bad:
+        return yhat_ref
+    _, Mc, h, w = yhat_ref.shape
+    return O.latent_from_symbols(sym_dev.reshape(1, -1).cpu(), Mc, h, w)
+
+
+def check_indices(total_ref, idx_dev, skip_locs, what):
+    """idx_dev [n_loc] against the oracle's totals [K, n_loc]: equal to the first argmin except on fp32 ties."""
+    total_ref = total_ref.reshape(total_ref.shape[0], -1)
+    want = total_ref.min(0)[1]
+    got = idx_dev.reshape(-1).cpu().long()
+    mism = [i for i in (want != got).nonzero().reshape(-1).tolist() if i not in skip_locs]
+    gaps = [float(total_ref[got[i], i] - total_ref[want[i], i]) for i in mism]
+    print(f"{what}: {len(mism)} / {got.numel()} prior indices differ from the oracle" +
+          (f" (largest gap between the two candidates: {max(gaps):.1e} bits)" if mism else ""))
+    assert all(g < TIE_BITS for g in gaps)
+    assert len(mism) <= max(2, int(2e-3 * got.numel()))
+    return len(mism)
+
+
+def test_kodak_batch_images_against_oracle(fast, dev, sd, table_f):
+    """Four of the benchmark's 24 768x512 inputs: symbols, prior indices, x_hat and coded size at that size."""
+    x = synth.rand_image(1000, 24, 512, 768)[[0, 7, 13, 23]]
+    streams, idx, h, w = fast.encode_batch(x.to(dev))
+    sym, idx2, _, _ = fast.encode_batch(x.to(dev), entropy_coding=False)
+    assert torch.equal(idx, idx2) and (h, w) == (32, 48)
+    recon = fast.decode_batch(streams, idx, h, w).clamp(0, 1).cpu()
+    table = O.renorm_cast_cdf(table_f, 16, O.ORDER_ROUND_THEN_ADD).numpy()
+    for i in range(4):
+        y = O.analysis(x[i:i + 1], sd)
+        bad = check_symbols(y, sym[i], f"768x512 image {i}")
+        total = O.prior_bits_lut_encode_layout(torch.round(y), table_f)
+        check_indices(total, idx[i], bad, f"768x512 image {i}")
+        want = O.synthesis(_latent(torch.round(y), sym[i], bad), sd).clamp(0, 1)
+        err = (recon[i:i + 1] - want).abs().max().item()
+        print(f"768x512 image {i}: x_hat max-abs error {err:.2e}")
+        assert err < 1e-2
+        # the device's bytes decode on the CPU specification decoder, and their number is within 0.5 % of the range coder's
+        idx_np, sym_np = idx[i].cpu().numpy().astype(np.int32), sym[i].cpu().numpy()
+        dev_table = fast.entropy_table_cpu.numpy()
+        assert np.array_equal(coders.mrs1_decode(dev_table, idx_np, streams[i]), sym_np)
+        ref = len(coders.range_encode_table(dev_table, idx_np, sym_np))
+        n_streams = int(np.frombuffer(streams[i][4:8], "<u4")[0])
+        print(f"768x512 image {i}: MRS1 {len(streams[i])} B in {n_streams} streams vs range coder {ref} B "
+              f"({100 * (len(streams[i]) - ref) / ref:+.3f} %)")
+        assert abs(len(streams[i]) - ref) / ref < 0.005
+    del table
+
+
+def test_training_shape_forward_against_oracle(fast, dev, sd):
+    """16 x 256x256: forward() (network-form likelihoods, log2) against the oracle's network form."""
+    x = synth.rand_image(2000, 16, 256, 256)
+    out = fast(x.to(dev))
+    ref = O.manypriors_forward(x, sd)
+    sym, _, h, w = fast.encode_batch(x.to(dev), entropy_coding=False)
+    bad = check_symbols(ref["y"], sym, "16x256x256 forward")
+    flips = len(bad)
+    check_indices(ref["total_bits"], fast.last_dist_select, bad, "16x256x256 forward")
+    assert float(out["bpp_feature"]) == pytest.approx(float(ref["bpp_feature"]), rel=2e-5)
+    assert float(out["bpp_sidestring"]) == pytest.approx(float(ref["bpp_sidestring"]), rel=1e-6) or bad
+    assert sorted(out["used_dists"]) == sorted(ref["used_dists"]) or bad
+    if not flips:
+        err = (out["reconstructed_image"].cpu() - ref["reconstructed_image"]).abs().max().item()
+        print(f"16x256x256 forward: x_hat max-abs error {err:.2e}, bpp {float(out['bpp']):.4f}")
+        assert err < 1e-2
+        assert float(out["visual_loss"]) == pytest.approx(float(ref["visual_loss"]), rel=2e-2)
+
+
+def test_4k_2160_against_oracle(fast, dev, sd, table_f):
+    """3840 x 2160: 135 latent rows (odd), so the four output phases of the transposed convolutions see borders of
+    different shapes.  Whole image: symbols, prior indices, lossless round trip, coded size, x_hat."""
+    from compression_amd import ops
+    x = synth.smooth_image(79, 1, 2160, 3840)
+    streams, idx, h, w = fast.encode_batch(x.to(dev))
+    assert (h, w) == (135, 240)
+    sym, _, _, _ = fast.encode_batch(x.to(dev), entropy_coding=False)
+    dec = ops.rans_decode_from_bytes(fast.entropy_table, idx.reshape(-1).to(torch.int32), streams)
+    assert torch.equal(dec.view(-1), sym.reshape(-1))
+    recon = fast.decode_batch(streams, idx, h, w)
+    assert recon.shape == (1, 3, 2160, 3840)
+    y = O.analysis(x, sd)
+    bad = check_symbols(y, sym[0], "3840x2160")
+    total = torch.cat([O.prior_bits_lut_encode_layout(torch.round(y)[:, :, r0:r0 + 27].contiguous(), table_f)
+                       for r0 in range(0, 135, 27)], dim=1)
+    check_indices(total, idx[0], bad, "3840x2160")
+    dev_table = fast.entropy_table_cpu.numpy()
+    idx_np, sym_np = idx[0].cpu().numpy().astype(np.int32), sym[0].cpu().numpy()
+    ref = len(coders.range_encode_table(dev_table, idx_np, sym_np))
+    print(f"3840x2160: MRS1 {len(streams[0])} B vs range coder {ref} B ({100 * (len(streams[0]) - ref) / ref:+.3f} %)")
+    assert abs(len(streams[0]) - ref) / ref < 0.005
+    want = O.synthesis(_latent(torch.round(y), sym[0], bad), sd).clamp(0, 1)
+    err = (recon.clamp(0, 1).cpu() - want).abs().max().item()
+    print(f"3840x2160: x_hat max-abs error {err:.2e}")
+    assert err < 1e-2
+
+
+@pytest.mark.parametrize("arch", ["ManyPriors_DC", "TestolinaManyPriors"])
+def test_jdc_1024_codec_against_oracle(dev, arch):
+    """JDC configuration: noisy 1024x1024 inputs, encode -> bytes -> decode, for the plain and the Testolina decoder."""
+    import compression_amd as ca
+    testolina = arch.startswith("Testolina")
+    sdm = synth.manypriors_state_dict(235, N, M, K, spread=True, testolina=testolina)
+    kw = dict(out_channel_N=N, out_channel_M=M, num_distributions=K, analysis_precision="f16x3", synthesis_precision="fp16")
+    m = ca.init_model("ManyPriors", dev, std_suffix="DC", **kw) if not testolina else ca.init_model(arch, dev, **kw)
+    assert type(m).__name__ == ("TestolinaManyPriors_ImageCompressor" if testolina else "ManyPriors_DC")
+    m.load_state_dict(sdm)
+    m.eval()
+    clean = synth.smooth_image(31, 2, 1024, 1024)
+    noisy = synth.noisy_image(clean, 32)
+    streams, idx, h, w = m.encode_batch(noisy.to(dev))
+    sym, _, _, _ = m.encode_batch(noisy.to(dev), entropy_coding=False)
+    recon = m.decode_batch(streams, idx, h, w).clamp(0, 1).cpu()
+    assert (h, w) == (64, 64) and recon.shape == noisy.shape
+    tf = O.entropy_table_float(sdm, M).contiguous()
+    synthesis = O.testolina_synthesis if testolina else O.synthesis
+    for i in range(2):
+        y = O.analysis(noisy[i:i + 1], sdm)
+        bad = check_symbols(y, sym[i], f"{arch} 1024x1024 image {i}")
+        check_indices(O.prior_bits_lut_encode_layout(torch.round(y), tf), idx[i], bad, f"{arch} 1024x1024 image {i}")
+        assert np.array_equal(coders.mrs1_decode(m.entropy_table_cpu.numpy(), idx[i].cpu().numpy().astype(np.int32), streams[i]),
+                              sym[i].cpu().numpy())
+        want = synthesis(_latent(torch.round(y), sym[i], bad), sdm).clamp(0, 1)
+        err = (recon[i:i + 1] - want).abs().max().item()
+        psnr_clean = 10 * math.log10(1.0 / float(((recon[i] - clean[i]) ** 2).mean()))
+        print(f"{arch} image {i}: x_hat max-abs error {err:.2e}; PSNR vs clean {psnr_clean:.2f} dB (random-init weights)")
+        assert err < 1e-2
+    # the one-image API of the reference, and forward() with no visual loss (lossf=None for JDC models)
+    bitstream, indices, h1, w1 = m.encode(noisy[:1].to(dev))
+    assert bitstream == streams[0] and torch.equal(indices.view(-1).to(torch.int32), idx[0])
+    out = m(noisy[:1].to(dev))
+    if not testolina:
+        assert out["visual_loss"] is None
+
+
+def test_testolina_hyperprior_forward(dev):
+    """TestolinaHP_ImageCompressor: hyperprior entropy model + the extended decoder, against the oracle's pieces."""
+    import compression_amd as ca
+    sdh = synth.transform_weights(237, N, M, testolina=True)
+    sdh.update(synth.hyperprior_weights(239, N, M))
+    m = ca.init_model("TestolinaHP", dev, out_channel_N=N, out_channel_M=M)
+    m.load_state_dict(sdh)
+    m.eval()
+    x = synth.smooth_image(41, 1, 128, 192)
+    out = m(x.to(dev))
+    y = O.analysis(x, sdh)
+    zhat = torch.round(O.hyper_analysis(y, sdh))
+    sigma = O.hyper_synthesis(zhat, sdh)
+    yhat = torch.round(y)
+    bits_y, _ = O.laplace_bits(yhat, sigma)
+    bits_z, _ = O.factorised_bits(zhat, sdh)
+    want = O.testolina_synthesis(yhat, sdh).clamp(0, 1)
+    npix = 128 * 192
+    err = (out["reconstructed_image"].cpu() - want).abs().max().item()
+    print(f"TestolinaHP: x_hat max-abs error {err:.2e}, bpp {float(out['bpp']):.4f}")
+    assert err < 1e-2
+    assert float(out["bpp_feature"]) == pytest.approx(float(bits_y) / npix, rel=1e-4)
+    assert float(out["bpp_sidestring"]) == pytest.approx(float(bits_z) / npix, rel=1e-4)
+    yq, zq = m.compress(x.to(dev))
+    assert (yq.cpu() != yhat).float().mean().item() <= 1e-5 and torch.equal(zq.cpu(), zhat)
+
+
+def test_device_tables_against_reference_capture(dev, sd, golden):
+    """The float table and both int16 tables built ON THE DEVICE against the rows captured from the reference
+    (tests/golden/tables_std.npz, every 37th (prior, channel) row).  The float chain evaluates its transcendental
+    functions correctly rounded where PyTorch's CPU kernels are within 1 ulp, so a few float entries differ in the
+    last bit; an int16 entry can then differ by one where the scaled value sits on a rounding tie."""
+    import compression_amd as ca
+    g = golden("tables_std")
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K)
+    m.load_state_dict(sd)
+    m.eval()
+    m.update_entropy_table()
+    rows = torch.from_numpy(g["rows"])
+    tf_dev = m.entropy_table_float.view(K * M, -1).cpu()[rows]
+    tf_ref = torch.from_numpy(g["table_f_rows"])
+    assert (tf_dev - tf_ref).abs().max().item() < 1e-6
+    same = (tf_dev == tf_ref).float().mean().item()
+    t_dev = m.entropy_table.view(K * M, -1).cpu()[rows]
+    d = (t_dev.int() - torch.from_numpy(g["table_torchac_rows"]).int())
+    frac = (d != 0).float().mean().item()
+    from compression_amd import abstract_model
+    t2 = abstract_model._renorm_cast_cdf_(m.entropy_table_float, 16).view(K * M, -1).cpu()[rows]
+    d2 = (t2.int() - torch.from_numpy(g["table_inrepo_rows"]).int())
+    frac2 = (d2 != 0).float().mean().item()
+    print(f"device tables vs reference capture ({rows.numel()} rows): float entries bit-identical {same:.4f}; "
+          f"int16 entries off by one: {frac:.2e} (round-then-add order), {frac2:.2e} (add-then-round order)")
+    assert d.abs().max().item() <= 1 and d2.abs().max().item() <= 1
+    assert frac < 5e-4 and frac2 < 5e-4
+    # the integer stage alone, fed the captured float rows, is exact in both orders
+    from compression_amd import ops
+    for order, key in ((0, "table_torchac_rows"), (1, "table_inrepo_rows")):
+        got = ops.renorm_cast_cdf(tf_ref.to(dev), 16, order).cpu()
+        assert torch.equal(got, torch.from_numpy(g[key]))

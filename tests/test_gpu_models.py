@@ -78,8 +78,20 @@ def test_forward_matches_reference(model, dev, golden, tag, x):
     err = (xhat - torch.from_numpy(g[f"{tag}_xhat"])).abs().max().item()
     print(f"[{tag}] x_hat max-abs error {err:.2e}")
     assert err < (1e-2 if nflip else 1e-4)
-    # prior indices (forward form): exact unless a symbol flipped or two priors tie exactly
-    out_idx = model._last_idx if hasattr(model, "_last_idx") else None
+    # prior indices (forward form) against the reference's capture: exact, except where the capture's own totals
+    # put the chosen prior within fp32 rounding of the minimum (an exact tie of two 256-term sums)
+    from compression_amd import ops
+    got_idx = model.last_dist_select.cpu().long().reshape(-1)
+    want_idx = torch.from_numpy(g[f"{tag}_idx"]).long().reshape(-1)
+    gold_total = torch.from_numpy(g[f"{tag}_total_bits"]).reshape(K, -1)
+    mism = (got_idx != want_idx).nonzero().reshape(-1)
+    gaps = gold_total[got_idx[mism], mism] - gold_total[want_idx[mism], mism]
+    print(f"[{tag}] prior-index mismatches {mism.numel()} / {got_idx.numel()}" +
+          (f" (largest gap {float(gaps.max()):.2e} bits)" if mism.numel() else ""))
+    assert nflip > 0 or mism.numel() == 0 or float(gaps.max()) < 1e-3
+    _, _, total = ops.prior_argmin(sym.view(-1, M), model._lut_log2, want_total=True)
+    if nflip == 0:
+        assert (total.cpu() - gold_total).abs().max().item() < 2e-3     # sums of 256 terms of up to 50 bits
     assert float(out["bpp_feature"]) == pytest.approx(float(g[f"{tag}_bpp_feature"]), rel=2e-5)
     assert float(out["bpp_sidestring"]) == pytest.approx(float(g[f"{tag}_bpp_sidestring"]), rel=1e-6)
     assert float(out["bpp"]) == pytest.approx(float(g[f"{tag}_bpp"]), rel=2e-5)
