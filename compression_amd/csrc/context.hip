@@ -42,6 +42,11 @@ int mpc_create(int device_id, void *stream, mpc_ctx **out) {
     c->device = device_id;
     c->stream = (hipStream_t)stream;
     c->err[0] = 0;
+    if (mpc_rans_static_init(c) != MPC_OK) {
+        fprintf(stderr, "libmpc: %s\n", c->err);
+        delete c;
+        return MPC_EHIP;
+    }
     *out = c;
     return MPC_OK;
 }

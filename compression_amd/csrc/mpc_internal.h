@@ -23,6 +23,9 @@ struct mpc_ctx {
 // ctx->stream and then calls mpc_ctx_scratch_release.
 void *mpc_ctx_scratch(mpc_ctx *ctx, size_t bytes);
 void mpc_ctx_scratch_release(mpc_ctx *ctx);
+// Looks up this device's instance of the static scratch of mpc_rans_decode_noalloc (rans.hip); the context's device
+// must be current.  Called by mpc_create.
+int mpc_rans_static_init(mpc_ctx *ctx);
 
 #define MPC_FAIL(ctx, code, ...)                                   \
     do {                                                           \

@@ -18,6 +18,14 @@
 // possible.
 #include "mpc_internal.h"
 
+// Scratch of the allocation-free decode entry point: the 16-byte aligned copy of the CDF table, at most
+// NOALLOC_MAX_ROWS rows (the standard model has K*M = 64*256 of them) of 528 bytes = 8.25 MiB per GPU, held until the
+// process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; kernels get the per-device address.
+constexpr int NOALLOC_MAX_ROWS = 64 * 256;
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_MAX_ROWS * 264 * sizeof(uint16_t);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static void *static_scratch_ptr[MPC_MAX_DEVICES] = {};
+
 namespace {
 
 constexpr uint32_t MRS1_MAGIC = 0x3153524Du;
@@ -301,6 +309,7 @@ constexpr int RING = 8;                    // LDS row slots per workgroup (power
 constexpr int INFLIGHT = 3;                // rows whose DMA may still be in flight behind the newest issued one
 constexpr int AHEAD = INFLIGHT + 1;        // barriers the loader runs ahead of the decoder
 constexpr int DMA_PITCH = 264;             // row pitch (entries) of the aligned table copy: 528 bytes
+static_assert(NOALLOC_SCRATCH_BYTES == (size_t)NOALLOC_MAX_ROWS * DMA_PITCH * sizeof(uint16_t), "static scratch size");
 constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
 
 // s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
@@ -668,4 +677,37 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     return rc;
 }
 
+// ---- decode without any allocation ------------------------------------------------------------------------------
+// mpc_rans_decode keeps its aligned copy of the table in context scratch that it allocates on demand.  Callers that
+// may not allocate (code under HIP graph capture, tight serving loops) use mpc_rans_decode_noalloc instead: the same
+// kernels, with the copy in the file-scope device array below.  Every GPU holds its own instance of the array at its
+// own address, found once per device by mpc_rans_static_init (called from mpc_create with that device current).
+int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const uint8_t *in,
+                            size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int n_streams,
+                            int locs_per_stream, int16_t *sym_out, int32_t *status_dev) {
+    MPC_ENTER(ctx);
+    Geometry g;
+    int rc = rans_decode_check(ctx, g, table, K, M, L, idx, in, in_stride, nbytes_dev, n_images, n_loc, n_streams,
+                               locs_per_stream, sym_out, status_dev);
+    if (rc) return rc;
+    MPC_REQUIRE(ctx, L == 257, "rans_decode_noalloc: only tables with 257 entries per row (256 symbols) are supported");
+    MPC_REQUIRE(ctx, (int64_t)K * M <= NOALLOC_MAX_ROWS,
+                "rans_decode_noalloc: K*M = %lld table rows exceed the static scratch (%d rows of %d bytes); use mpc_rans_decode",
+                (long long)K * M, NOALLOC_MAX_ROWS, DMA_PITCH * 2);
+    void *aligned = ctx->device >= 0 && ctx->device < MPC_MAX_DEVICES ? static_scratch_ptr[ctx->device] : nullptr;
+    MPC_REQUIRE(ctx, aligned != nullptr, "rans_decode_noalloc: the static scratch of device %d was not initialised", ctx->device);
+    // align_rows_kernel rewrites every byte of the K*M rows this call reads, so the previous call's contents never show
+    return rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+}
+
 }  // extern "C"
+
+int mpc_rans_static_init(mpc_ctx *ctx) {
+    const int d = ctx->device;
+    if (d < 0 || d >= MPC_MAX_DEVICES) return MPC_OK;            // such a device gets no static scratch (the entry point says so)
+    if (static_scratch_ptr[d]) return MPC_OK;
+    void *p = nullptr;
+    MPC_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    static_scratch_ptr[d] = p;
+    return MPC_OK;
+}

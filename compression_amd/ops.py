@@ -280,6 +280,22 @@ def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbyt
     return sym, status
 
 
+def rans_decode_noalloc(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int,
+                        n_streams: int, locs_per_stream: int, sym_out: torch.Tensor, status_out: torch.Tensor) -> None:
+    """mpc_rans_decode_noalloc: the decode of rans_decode into caller-provided sym_out (int16 [n_images, n_loc*M]) and
+    status_out (int32 [n_images]); neither this wrapper nor the library allocates device memory.  Standard tables
+    only (L = 257, K*M <= 16384); calls that overlap in time on one GPU race on the library's static scratch."""
+    _dev(table, torch.int16, "table"); _dev(idx, torch.int32, "idx"); _dev(data, torch.uint8, "data")
+    _dev(nbytes, torch.int64, "nbytes"); _dev(sym_out, torch.int16, "sym_out"); _dev(status_out, torch.int32, "status_out")
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    if sym_out.numel() != n_images * n_loc * M or status_out.numel() != n_images:
+        raise MpcError("rans_decode_noalloc: sym_out / status_out have the wrong size")
+    stride = data.shape[-1] if data.dim() == 2 else data.numel() // n_images
+    context_for(table.device).call("mpc_rans_decode_noalloc", ptr(table), K, M, L, ptr(idx), ptr(data), stride, ptr(nbytes),
+                                   n_images, n_loc, n_streams, locs_per_stream, ptr(sym_out), ptr(status_out))
+
+
 # ---- image-quality statistics ------------------------------------------------------------------------
 def ssim_stats(x: torch.Tensor, y: torch.Tensor, window: Sequence[float], C1: float, C2: float):
     """x, y NCHW fp32 -> (mean SSIM map, mean contrast-structure map) per (image, channel), float64 [B, C]."""

@@ -149,6 +149,16 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
                     int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
                     int32_t *status_dev);
 
+/* Same as mpc_rans_decode, for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): it calls no allocating routine.  It has no counterpart in the
+ * reference.  The aligned table copy lives in a static device array of the library instead of context scratch:
+ * L must be 257 and K*M at most 16384 rows (8.25 MiB per GPU, held until the process ends), otherwise MPC_EINVAL.
+ * All calls on one GPU share that array: calls that overlap in time on one GPU (two streams, two contexts) race. */
+int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                            const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
+                            int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
+                            int32_t *status_dev);
+
 /* ---- transform layers ---------------------------------------------------------------------- */
 enum { MPC_CONV = 0, MPC_DECONV = 1 };
 enum {
