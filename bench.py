@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""Benchmark of the Manypriors codec inference path on MI355X.
+"""Benchmark of the Manypriors / JDC codec inference path on MI355X.
 
-Workload (the configuration the encode+decode metric is quoted on): the full codec
-on a batch of 24 synthetic Kodak-shaped 768x512 images per GPU with the standard model (N=192, M=256, K=64,
-random-init transforms, spread priors): one STEP =
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1..5]
+
+Workloads (--config, default 3 = the configuration the encode+decode metric is quoted on):
+    1  std Manypriors, 1 x 768x512, eval forward (x_hat + bpp estimate)            forward MP/s
+    2  training shape, 16 x 256x256 crops, eval forward                           forward MP/s
+    3  full codec on 24 x 768x512 per GPU                                         encode+decode MP/s
+    4  full codec on one 3840x2160 image per GPU per step                         encode+decode MP/s
+    5  JDC: ManyPriors_DC (or --arch TestolinaManyPriors) on 8 noisy 1024x1024 per GPU, full codec
+One codec STEP =
     encode:  g_a -> round -> symbols -> prior competition -> MRS1 rANS -> byte strings on the host
     decode:  byte strings -> rANS decode -> latent -> g_s -> clamp -> x_hat on the device
-with the input batch already resident in HBM.  value = megapixels (B*H*W of the input) per second over all
-ranks.  Images are independent, so N GPUs run N independent batches (weak scaling, no data-path collective);
-the only collective is one all-reduce of a 16-double statistics vector per step.
+    + per-image squared error and the batch's statistics vector (one 16-double all-reduce when N > 1)
+with the input batch already resident in HBM.  value = megapixels (B*H*W of the input) per second over all ranks.
 
-Extra objects on the JSON line: "roofline" for the dominant kernel (the implicit-GEMM conv with fused GDN of the
-analysis transform; achieved = algorithmic FLOP / HIP-event time, traffic = bytes per launch from the committed
-counter passes), "cpu_baseline" (the CPU oracle timed on this host on a bounded sample), "kernels" (per-kernel achieved
-rates of the other launches, including the materialised CDF build that the fused coder does not need).
+N GPUs: images are independent, every rank codes its own batch (weak scaling, no data-path collective).  Started as
+`python bench.py --gpus N` the script starts N child processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set per child) before it touches any GPU, and relays rank 0's JSON line; started by torch.distributed.run it
+takes its rank from the environment.  --dry-run rehearses the launcher and the statistics path on the CPU (gloo).
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (achieved = algorithmic FLOP / HIP-event time;
+traffic = bytes per launch from the committed counter passes, null if they were taken on other kernel sources),
+"cdf_build" (the materialised per-symbol CDF rows at the workload's size, which the fused coder never needs),
+"hbm_ceiling" (device copy / fill rates measured in this run), "cpu_baseline" (the CPU oracle timed on this host),
+"kernels" (per-launch rates), "stats" (the all-reduced evaluation statistics of one step).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +44,23 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # dense fp32-input MFMA peak, MI355X
 PEAK_F16_MFMA_TFLOPS = 2500.0    # dense fp16/bf16 MFMA peak, MI355X
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    1: dict(arch="ManyPriors", batch=1, height=512, width=768, mode="forward", data="rand",
+            what="std Manypriors forward + bpp estimate on one 768x512 image"),
+    2: dict(arch="ManyPriors", batch=16, height=256, width=256, mode="forward", data="rand",
+            what="training-shape eval forward on 16 x 256x256 crops"),
+    3: dict(arch="ManyPriors", batch=24, height=512, width=768, mode="codec", data="rand",
+            what="full codec (encode -> bytes -> decode) on 24 x 768x512 images"),
+    4: dict(arch="ManyPriors", batch=1, height=2160, width=3840, mode="codec", data="rand",
+            what="full codec on one 3840x2160 image"),
+    5: dict(arch="ManyPriors_DC", batch=8, height=1024, width=1024, mode="codec", data="noisy",
+            what="JDC full codec on 8 noisy 1024x1024 images"),
+}
+# sources whose change invalidates the committed counter passes of the dominant kernel
+TRAFFIC_SOURCES = ("compression_amd/csrc/conv_igemm_x3.hip", "compression_amd/csrc/conv_common.h")
+PMC_TABLE = os.path.join(REPO, "profiles", "r2_pmc_counters.csv")
+PMC_META = os.path.join(REPO, "profiles", "r2_pmc_meta.json")
+
 
 def kernel_peak(name):
     """(peak TFLOP/s of the MFMA type the kernel issues, MFMA instructions issued per algorithmic product)."""
@@ -40,105 +71,316 @@ def kernel_peak(name):
     return PEAK_F32_MFMA_TFLOPS, 1
 
 
+def sources_digest():
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(REPO, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 counter passes (profiles/r1_pmc_counters.csv,
-    made by tools/pmc_run.sh: one --pmc pass for FETCH_SIZE, one for WRITE_SIZE; FETCH_SIZE doubled as gfx950 tallies
-    its 128-byte read requests at 64 bytes).  None when the table has no row for the kernel."""
+    """-> (HBM-side bytes per launch of `kernel`, commit the counters were taken at) from the committed rocprofv3
+    counter passes (tools/pmc_run.sh: one --pmc pass for FETCH_SIZE, one for WRITE_SIZE; FETCH_SIZE doubled: gfx950
+    tallies its 128-byte read requests at 64 bytes, checked against a copy of known size in the same pass).  (None, ...)
+    when the table has no row for the kernel or was taken on other sources of that kernel than the ones here."""
     import csv
-    path = os.path.join(REPO, "profiles", "r1_pmc_counters.csv")
-    if not os.path.exists(path):
-        return None
-    with open(path, newline="") as f:
+    if not (os.path.exists(PMC_TABLE) and os.path.exists(PMC_META)):
+        return None, None
+    meta = json.load(open(PMC_META))
+    if meta.get("sources_sha256_16") != sources_digest():
+        return None, meta.get("commit")
+    with open(PMC_TABLE, newline="") as f:
         for r in csv.DictReader(f):
             if kernel in r["Kernel"] and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
-                return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
-    return None
+                return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, meta.get("commit")
+    return None, meta.get("commit")
 
 
-def parse():
-    ap = argparse.ArgumentParser()
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24)
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--data", default="rand", choices=["rand", "smooth"])
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--arch", default=None, help="model class (default: the config's; e.g. TestolinaManyPriors for config 5)")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--data", default=None, choices=["rand", "smooth", "noisy"])
     ap.add_argument("--analysis-precision", default="f16x3", choices=["fp32", "f16x3"],
                     help="g_a arithmetic: exact f32 MFMA, or split-precision fp16 MFMA (fp32-grade, same symbols)")
     ap.add_argument("--synthesis-precision", default="fp16", choices=["fp32", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=48)
-    return ap.parse_args()
+    ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU baseline's sample at the larger thread count")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo ranks on the CPU with a stub step, to rehearse the launcher and the statistics path")
+    args = ap.parse_args(argv)
+    cfg = CONFIGS[args.config]
+    for k in ("arch", "batch", "height", "width", "data"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
+    args.mode = cfg["mode"]
+    return args
 
 
-def cpu_baseline(n_images, H, W):
-    """The CPU oracle (PyTorch-CPU fp32 restatement + C range coder) on n_images images, all host threads
-    torch was given.  Timed: g_a, round, LUT competition, range encode, range decode, g_s."""
+# ---- launcher -----------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def child_env(rank, world, port, base=None):
+    """Environment of rank `rank` of `world` single-node ranks."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL over xGMI needs it on this driver
+    return env
+
+
+def spawn_ranks(args, argv):
+    """Parent of `python bench.py --gpus N`: starts N fresh children (this process never initialises a GPU), waits,
+    relays rank 0's JSON line.  Returns the exit code."""
+    if not args.dry_run:
+        n = torch.cuda.device_count()                      # counting devices does not initialise the GPU
+        if n < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible", file=sys.stderr)
+            return 2
+    port = free_port()
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(args.gpus):
+        procs.append(subprocess.Popen(cmd, env=child_env(r, args.gpus, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if any(rcs) or not lines:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+        return next((rc for rc in rcs if rc), 1)
+    print(lines[-1])
+    return 0
+
+
+def rank_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def device_for(local_rank, dry_run):
+    """Rank -> device: one process per GPU, cuda:LOCAL_RANK (the CPU in a dry run)."""
+    return torch.device("cpu") if dry_run else torch.device("cuda", local_rank)
+
+
+def init_distributed(args, dev, world):
+    """Process group of the run (None for one rank): RCCL ("nccl") on GPUs, gloo in a dry run."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    if args.dry_run:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=dev)
+    if dist.get_world_size() != world or (args.gpus != world):
+        raise RuntimeError(f"--gpus {args.gpus}, WORLD_SIZE {world}, process group of {dist.get_world_size()} ranks disagree")
+    return dist
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------
+def host_cpu():
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return {"model": model, "physical_cores": len(phys) or None, "logical_cpus": logical or os.cpu_count()}
+
+
+def cpu_baseline_run(n_images, H, W, threads):
+    """The CPU oracle (PyTorch-CPU fp32 restatement + C range coder) on n_images images with `threads` host threads,
+    per stage under the reference's timing_analysis keys (manynets_compressor.py:394-401)."""
     import numpy as np
     from oracle import coders, manypriors_oracle as O
     from tests import synth
     torch.set_grad_enabled(False)
+    torch.set_num_threads(threads)
     sd = synth.manypriors_state_dict(234)
     tf = O.entropy_table_float(sd, 256).contiguous()
-    table = O.renorm_cast_cdf(tf, 16, O.ORDER_ROUND_THEN_ADD).numpy()
+    table_t = O.renorm_cast_cdf(tf, 16, O.ORDER_ROUND_THEN_ADD)
+    table = table_t.numpy()
     x = synth.rand_image(99, n_images, H, W)
     O.analysis(x[:1, :, :64, :64], sd)                      # warm the thread pool
-    t0 = time.perf_counter()
+    st = dict.fromkeys(("nnenc", "getindices_lut", "make_cdf_tbl", "torchac_enc", "torchac_dec", "nndec"), 0.0)
+    t_all = time.perf_counter()
     for i in range(n_images):
+        t = time.perf_counter()
         yhat = O.quantise(O.analysis(x[i:i + 1], sd))
+        st["nnenc"] += time.perf_counter() - t
         _, M, h, w = yhat.shape
+        t = time.perf_counter()
         _, idx = O.prior_bits_lut_encode_layout(yhat, tf).min(0)
+        st["getindices_lut"] += time.perf_counter() - t
+        t = time.perf_counter()
+        rows = O.gather_cdf(table_t, idx)                   # the materialised per-symbol rows of the reference's encode
+        st["make_cdf_tbl"] += time.perf_counter() - t
+        del rows
         sym = O.symbols_from_latent(yhat).flatten().numpy()
         idx32 = idx.reshape(-1).numpy().astype(np.int32)
+        t = time.perf_counter()
         data = coders.range_encode_table(table, idx32, sym)
+        st["torchac_enc"] += time.perf_counter() - t
+        t = time.perf_counter()
         dec = coders.range_decode_table(table, idx32, data)
+        st["torchac_dec"] += time.perf_counter() - t
+        t = time.perf_counter()
         lat = O.latent_from_symbols(torch.from_numpy(dec).view(1, -1), M, h, w)
         O.synthesis(lat, sd).clamp(0, 1)
+        st["nndec"] += time.perf_counter() - t
+    dt = time.perf_counter() - t_all
+    return {"value": n_images * H * W / 1e6 / dt, "unit": "megapixels/s", "cores": threads, "images": n_images,
+            "seconds": dt, "stage_ms_per_image": {k: 1e3 * v / n_images for k, v in st.items()}}
+
+
+def cpu_baseline(n_images, H, W):
+    """Two bounded samples of the workload's images: at the host threads this process was given (the GPU box's CPU share;
+    the machine's core counts are reported beside it) and at 8 threads."""
+    share = torch.get_num_threads()
+    runs = [cpu_baseline_run(n_images, H, W, share)]
+    if share != 8:
+        runs.append(cpu_baseline_run(max(2, n_images // 2), H, W, min(8, share)))
+    torch.set_num_threads(share)
+    main = runs[0]
+    return {"value": main["value"], "unit": "megapixels/s", "cores": main["cores"], "kind": "port",
+            "sample": f"{main['images']} of the {H}x{W} images, encode+decode incl. the materialised CDF rows, "
+                      f"{main['seconds']:.1f} s at {main['cores']} threads" +
+                      (f"; {runs[1]['images']} images, {runs[1]['seconds']:.1f} s at {runs[1]['cores']} threads" if len(runs) > 1 else ""),
+            "host": host_cpu(), "runs": runs}
+
+
+# ---- measured ceilings -------------------------------------------------------------------------------------------
+def hbm_ceiling(dev, nbytes=1 << 31):
+    """Device copy and fill rates of this GPU (GB/s of bytes moved), next to the 8 TB/s datasheet figure."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, fn, moved in (("copy", lambda: b.copy_(a), 2 * nbytes), ("fill", lambda: a.zero_(), nbytes)):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_gb_per_s"] = moved * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
+
+
+# ---- the runs -------------------------------------------------------------------------------------------------------
+def run_dry(args, rank, world):
+    """Launcher / statistics rehearsal on the CPU: every rank "codes" args.batch images with made-up but rank- and
+    image-dependent numbers through StatsAccumulator and the all-reduce, and rank 0 prints the reduced sums."""
+    from compression_amd.distributed import StatsAccumulator
+    dev = device_for(int(os.environ.get("LOCAL_RANK", "0")), True)
+    dist = init_distributed(args, dev, world)
+    H, W = args.height, args.width
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        acc = StatsAccumulator()
+        for i in range(args.batch):
+            g = rank * args.batch + i
+            acc.add_image(bits=1000.0 * (g + 1), pixels=H * W, sq_err=0.5 * (g + 1), nbytes=125 * (g + 1), seconds=0.01,
+                          msssim=0.9 + 0.001 * g)
+        acc.all_reduce()
+    if dist is not None:
+        dist.barrier()
     dt = time.perf_counter() - t0
-    return {"value": n_images * H * W / 1e6 / dt, "unit": "megapixels/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{n_images} of the {H}x{W} images, encode+decode, {dt:.1f} s of CPU time"}
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no codec work)", "value": 0.0, "unit": "megapixels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+                          "device": str(dev), "backend": "gloo" if dist is not None else None,
+                          "env": {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")},
+                          "stats": acc.result()}))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+def make_inputs(args, rank, dev):
+    """-> (model input, the image the reconstruction is scored against), both resident on the device."""
+    from tests import synth
+    B, H, W = args.batch, args.height, args.width
+    if args.data == "noisy":
+        clean = synth.smooth_image(1000 + rank, B, H, W)
+        return synth.noisy_image(clean, 2000 + rank).to(dev), clean.to(dev)
+    gen = synth.rand_image if args.data == "rand" else synth.smooth_image
+    x = gen(1000 + rank, B, H, W).to(dev)
+    return x, x
+
+
+def run_rank(args):
+    rank, world, local = rank_env()
+    if args.dry_run:
+        return run_dry(args, rank, world)
+    dev = device_for(local, False)
+    torch.cuda.set_device(dev)
+    dist = init_distributed(args, dev, world)
     torch.set_grad_enabled(False)
 
     import compression_amd as ca
-    from compression_amd import ops
+    from compression_amd import ops, pt_ms_ssim
+    from compression_amd.distributed import StatsAccumulator
     from tests import synth
 
-    model = ca.init_model("ManyPriors", dev, out_channel_N=192, out_channel_M=256, num_distributions=64,
-                          analysis_precision=args.analysis_precision, synthesis_precision=args.synthesis_precision)
-    model.load_state_dict(synth.manypriors_state_dict(234))
+    testolina = args.arch.startswith("Testolina")
+    kw = dict(out_channel_N=192, out_channel_M=256, num_distributions=64, analysis_precision=args.analysis_precision,
+              synthesis_precision=args.synthesis_precision)
+    model = ca.init_model("ManyPriors", dev, std_suffix="DC", **kw) if args.arch == "ManyPriors_DC" else ca.init_model(args.arch, dev, **kw)
+    model.load_state_dict(synth.manypriors_state_dict(234, testolina=testolina))
     model.eval()
-    gen = synth.rand_image if args.data == "rand" else synth.smooth_image
-    x = gen(1000 + rank, args.batch, args.height, args.width).to(dev)
+    x, target = make_inputs(args, rank, dev)
     B, _, H, W = x.shape
     mp_per_step = B * H * W / 1e6
-    stats = torch.zeros(16, dtype=torch.float64, device=dev)
+    acc = StatsAccumulator(device=dev)
+    state = {"seconds": 0.0}
 
-    def step():
+    def codec_step():
         streams, idx, h, w = model.encode_batch(x)
         recon = model.decode_batch(streams, idx, h, w)
-        xhat, sse = ops.clamp_sse(recon, x)
-        stats.zero_()
-        stats[0] = sum(len(s) for s in streams) * 8.0      # bits
-        stats[1] = B * H * W                                # pixels
-        stats[2:3] = sse
-        stats[3] = B
-        if dist is not None:
-            dist.all_reduce(stats)
-        return streams, xhat
+        xhat, sse = ops.clamp_sse_per_image(recon, target)
+        nbytes = float(sum(len(s) for s in streams))
+        acc.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
+        acc.all_reduce()
+        return xhat
+
+    def forward_step():
+        out = model(x)                                      # reads bpp back on the host, like the reference's test_dir
+        xhat = out["reconstructed_image"]
+        _, sse = ops.clamp_sse_per_image(xhat, target)
+        bits = float(out["bpp_feature"]) * B * H * W
+        acc.add_batch_device(sse, 3 * H * W, bits=bits, pixels=B * H * W, nbytes=bits / 8, seconds=state["seconds"],
+                             side_bits=float(out["bpp_sidestring"]) * B * H * W, reset=True)
+        acc.all_reduce()
+        return xhat
+
+    step = codec_step if args.mode == "codec" else forward_step
 
     def barrier():
         if dist is not None:
@@ -146,12 +388,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
+        t = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        state["seconds"] = time.perf_counter() - t
     prof = ops.PROFILER = ops.Profiler()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        streams, xhat = step()
+        xhat = step()
     barrier()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
@@ -161,26 +406,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # the materialised per-symbol CDF rows ("CDF build"): measured on its own, the fused coder never needs it
-    n_loc_probe = min(4096, B * (H // 16) * (W // 16))
+    # evaluation statistics of one step with MS-SSIM (outside the timed region: the codec step does not need it)
+    state["seconds"] = dt / args.steps
+    stats = None
+    try:
+        ms = pt_ms_ssim.ms_ssim(xhat, target, data_range=1.0, size_average=False).to(torch.float64).contiguous()
+    except AssertionError:
+        ms = None                                           # image too small for the 5 scales
+    _, sse = ops.clamp_sse_per_image(xhat, target)
+    rep = StatsAccumulator(device=dev)
+    last = acc.result()
+    rep.add_batch_device(sse, 3 * H * W, bits=last["bits"] / world, pixels=B * H * W, nbytes=last["bytes"] / world,
+                         seconds=state["seconds"], side_bits=last["side_bits"] / world, msssim=ms, reset=True)
+    stats = rep.all_reduce().result()
+
+    # the materialised per-symbol CDF rows ("CDF build") at the workload's size: measured on its own, the fused coder
+    # never needs this tensor
+    n_loc_probe = min(36864, B * (H // 16) * (W // 16))
     idx_probe = torch.randint(0, 64, (n_loc_probe,), dtype=torch.int32, device=dev)
-    ops.gather_cdf(model.entropy_table, idx_probe)
+    model._ensure_tables()
+    rows = ops.gather_cdf(model.entropy_table, idx_probe)
     p2 = ops.PROFILER = ops.Profiler()
     for _ in range(5):
-        ops.gather_cdf(model.entropy_table, idx_probe)
+        ops.gather_cdf(model.entropy_table, idx_probe, out=rows)
     ops.PROFILER = None
     kern.update(p2.summary())
+    del rows
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
-    bits = float(stats[0].item())
+        return 0
     value = world * mp_per_step * args.steps / dt
-    dom = max((k for k in kern if k.startswith("conv_igemm")), key=lambda k: kern[k]["ms"])
+    conv = [k for k in kern if k.startswith("conv_igemm")]
+    dom = max(conv, key=lambda k: kern[k]["ms"])
     d = kern[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     peak, passes = kernel_peak(dom)
+    traffic, profiled_at = pmc_traffic(dom)
     kernels = {}
     for k, v in kern.items():
         e = {"calls_per_step": v["calls"] / (5 if k == "gather_cdf" else args.steps), "avg_ms": v["ms"] / v["calls"]}
@@ -189,32 +452,46 @@ def main():
         if v["bytes"]:
             e["gb_per_s"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         kernels[k] = e
+    metric = "encode+decode megapixels/sec" if args.mode == "codec" else "eval forward megapixels/sec"
     out = {
-        "metric": "encode+decode megapixels/sec", "value": value, "unit": "megapixels/s", "n_gpus": world,
+        "metric": metric, "value": value, "unit": "megapixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "f16x3": "f16 hi/lo split x3 (fp32-grade), f32 accumulate"}[args.analysis_precision]
                  + " (g_a); " + {"fp32": "f32", "fp16": "f16, f32 accumulate"}[args.synthesis_precision] + " (g_s)",
         "data": "synthetic",
-        "config": {"workload": f"full codec (encode -> bytes -> decode) on {B} x {W}x{H} images per GPU, std Manypriors "
-                               f"N=192 M=256 K=64, random-init weights with spread priors, {args.data} input",
-                   "images_per_gpu": B, "height": H, "width": W, "bpp": bits / (world * B * H * W),
-                   "parallelism": f"image-sharded x{world}, stats all-reduce only"},
+        "config": {"workload": f"config {args.config}: {CONFIGS[args.config]['what']} per GPU, {args.arch} N=192 M=256 K=64, "
+                               f"random-init weights with spread priors, {args.data} input",
+                   "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
+                   "parallelism": f"image-sharded x{world}, statistics all-reduce only"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(dom),
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,
                      "avg_launch_ms": d["ms"] / d["calls"], "launches_per_step": d["calls"] / args.steps},
         "kernels": kernels,
+        "stats": stats,
     }
     if "gather_cdf" in kernels:
         out["cdf_build"] = {"bound": "hbm", "achieved": kernels["gather_cdf"]["gb_per_s"], "peak": PEAK_HBM_GBS,
-                            "unit": "GB/s", "frac": kernels["gather_cdf"]["gb_per_s"] / PEAK_HBM_GBS}
+                            "unit": "GB/s", "frac": kernels["gather_cdf"]["gb_per_s"] / PEAK_HBM_GBS,
+                            "locations": n_loc_probe, "bytes": n_loc_probe * 256 * 257 * 2}
+    out["hbm_ceiling"] = hbm_ceiling(dev)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_images, H, W)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_images, 512, 768) if args.config == 3 else \
+            cpu_baseline(max(2, min(args.cpu_images, int(16 * 393216 / (H * W)) or 2)), H, W)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

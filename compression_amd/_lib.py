@@ -46,6 +46,8 @@ SIGNATURES = {
     "mpc_symbols_to_latent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mpc_sum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_clamp_sse": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mpc_clamp_sse_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "mpc_stats_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, POINTER(c_double), c_int, c_void_p]),
     "mpc_ssim_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_float), c_int, c_float, c_float,
                                c_void_p, c_void_p]),
     "mpc_avg_pool2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

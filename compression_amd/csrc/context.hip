@@ -137,42 +137,46 @@ __global__ void sum_f32_kernel(const float *__restrict__ x, int64_t n, double *_
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
-// 16 bytes per lane and access, two accesses in flight per array; differences squared in fp32, summed in fp64
+// 16 bytes per lane and access, two accesses in flight per array; differences squared in fp32, summed in fp64.
+// blockIdx.y = image: image i covers elements [i*n, (i+1)*n) and owns sse[i].  score_clamped: the error is taken on
+// the clamped value (the PSNR of the test harness) instead of the raw reconstruction (the model's visual loss).
 __global__ void clamp_sse_kernel(const float *__restrict__ recon, const float *__restrict__ target, int64_t n,
-                                 float *__restrict__ xhat, double *__restrict__ sse, int aligned16) {
+                                 float *__restrict__ xhat, double *__restrict__ sse, int aligned16, int score_clamped) {
+    const int64_t img_off = (int64_t)blockIdx.y * n;
+    recon += img_off;
+    if (target) target += img_off;
+    if (xhat) xhat += img_off;
+    if (sse) sse += blockIdx.y;
     double acc = 0.0;
     const int64_t n4 = aligned16 ? n >> 2 : 0, stride = (int64_t)gridDim.x * blockDim.x;
     const float4 *r4 = (const float4 *)recon, *t4 = (const float4 *)target;
     float4 *x4 = (float4 *)xhat;
-    auto one = [&](const float4 &r, int64_t i) {
-        if (xhat) x4[i] = make_float4(fminf(fmaxf(r.x, 0.0f), 1.0f), fminf(fmaxf(r.y, 0.0f), 1.0f),
-                                      fminf(fmaxf(r.z, 0.0f), 1.0f), fminf(fmaxf(r.w, 0.0f), 1.0f));
+    auto clamp4 = [](const float4 &r) {
+        return make_float4(fminf(fmaxf(r.x, 0.0f), 1.0f), fminf(fmaxf(r.y, 0.0f), 1.0f), fminf(fmaxf(r.z, 0.0f), 1.0f),
+                           fminf(fmaxf(r.w, 0.0f), 1.0f));
     };
     auto sq = [&](const float4 &r, const float4 &t) {
         float a = r.x - t.x, b = r.y - t.y, c = r.z - t.z, d = r.w - t.w;
         acc += (double)(a * a) + (double)(b * b) + (double)(c * c) + (double)(d * d);
     };
+    auto one = [&](const float4 &r, int64_t i) {
+        const float4 c = clamp4(r);
+        if (target) sq(score_clamped ? c : r, t4[i]);
+        if (xhat) x4[i] = c;
+    };
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
         float4 ra = r4[i], rb = r4[i + stride];
-        if (target) {
-            float4 ta = t4[i], tb = t4[i + stride];
-            sq(ra, ta);
-            sq(rb, tb);
-        }
         one(ra, i);
         one(rb, i + stride);
     }
-    for (; i < n4; i += stride) {
-        float4 ra = r4[i];
-        if (target) sq(ra, t4[i]);
-        one(ra, i);
-    }
+    for (; i < n4; i += stride) one(r4[i], i);
     for (int64_t k = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {   // tail
         float r = recon[k];
-        if (xhat) xhat[k] = fminf(fmaxf(r, 0.0f), 1.0f);
+        float c = fminf(fmaxf(r, 0.0f), 1.0f);
+        if (xhat) xhat[k] = c;
         if (target) {
-            float d = r - target[k];
+            float d = (score_clamped ? c : r) - target[k];
             acc += (double)(d * d);
         }
     }
@@ -217,8 +221,24 @@ int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t
     int64_t blocks = mpc_cdiv(n, 256 * 4);
     if (blocks > 4096) blocks = 4096;
     const int aligned16 = (((uintptr_t)recon | (uintptr_t)target | (uintptr_t)xhat) & 15) == 0;
-    clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev, aligned16);
+    clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev, aligned16, 0);
     MPC_CHECK_LAUNCH(ctx, "clamp_sse");
+    return MPC_OK;
+}
+
+int mpc_clamp_sse_batched(mpc_ctx *ctx, const float *recon, const float *target, int n_images, int64_t n_per_image,
+                          int score_clamped, float *xhat, double *sse_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, recon && n_images > 0 && n_images < 65536 && n_per_image > 0 && (xhat || (sse_dev && target)),
+                "clamp_sse_batched: bad arguments");
+    if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double) * n_images, ctx->stream));
+    int64_t blocks = mpc_cdiv(n_per_image, 256 * 4);
+    const int64_t cap = mpc_cdiv(4096, n_images);
+    if (blocks > cap) blocks = cap;
+    const int aligned16 = ((((uintptr_t)recon | (uintptr_t)target | (uintptr_t)xhat) & 15) == 0) && (n_per_image % 4 == 0);
+    clamp_sse_kernel<<<dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, ctx->stream>>>(
+        recon, sse_dev ? target : nullptr, n_per_image, xhat, sse_dev, aligned16, score_clamped);
+    MPC_CHECK_LAUNCH(ctx, "clamp_sse_batched");
     return MPC_OK;
 }
 

@@ -101,9 +101,58 @@ __global__ void avg_pool2_kernel(const float *__restrict__ in, int64_t planes, i
     out[i] = s * 0.25f;
 }
 
+// Running sums of the evaluation statistics of a batch (layout documented at mpc_stats_accumulate).  One wave.
+struct HostSums {
+    double bits, pixels, bytes, seconds, side_bits;
+};
+
+__global__ __launch_bounds__(64) void stats_accumulate_kernel(const double *__restrict__ sse, const double *__restrict__ msssim,
+                                                              int n_images, double values_per_image, HostSums hs,
+                                                              int reset, double *__restrict__ vec) {
+    double sq = 0.0, psnr = 0.0, ms = 0.0, msdb = 0.0;
+    for (int i = threadIdx.x; i < n_images; i += 64) {
+        const double e = sse[i];
+        sq += e;
+        const double mse = e / values_per_image;
+        psnr += mse > 0.0 ? 10.0 * log10(1.0 / mse) : (double)__builtin_inff();
+        if (msssim) {
+            const double m = msssim[i];
+            ms += m;
+            if (m > 0.0 && m < 1.0) msdb += -10.0 * log10(1.0 - m);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sq += __shfl_down(sq, off, 64);
+        psnr += __shfl_down(psnr, off, 64);
+        ms += __shfl_down(ms, off, 64);
+        msdb += __shfl_down(msdb, off, 64);
+    }
+    // lane i owns vec[i]: no lane reads what another lane has just written
+    sq = __shfl(sq, 0, 64); psnr = __shfl(psnr, 0, 64); ms = __shfl(ms, 0, 64); msdb = __shfl(msdb, 0, 64);
+    const double add[16] = {hs.bits, hs.pixels, sq, psnr, (double)n_images, hs.bytes, hs.seconds, hs.side_bits, ms, msdb,
+                            0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (threadIdx.x < 16) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((int)threadIdx.x == k) v = add[k];
+        vec[threadIdx.x] = (reset ? 0.0 : vec[threadIdx.x]) + v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int mpc_stats_accumulate(mpc_ctx *ctx, const double *sse_dev, const double *msssim_dev, int n_images,
+                         int64_t values_per_image, const double host_sums[5], int reset, double *vec_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, sse_dev && host_sums && vec_dev && n_images > 0 && values_per_image > 0, "stats_accumulate: bad arguments");
+    HostSums hs = {host_sums[0], host_sums[1], host_sums[2], host_sums[3], host_sums[4]};
+    stats_accumulate_kernel<<<dim3(1), dim3(64), 0, ctx->stream>>>(sse_dev, msssim_dev, n_images, (double)values_per_image, hs, reset, vec_dev);
+    MPC_CHECK_LAUNCH(ctx, "stats_accumulate");
+    return MPC_OK;
+}
 
 int mpc_ssim_stats(mpc_ctx *ctx, const float *x, const float *y, int planes, int H, int W, const float *window,
                    int win_size, float C1, float C2, double *ssim_sum_dev, double *cs_sum_dev) {

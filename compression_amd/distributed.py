@@ -37,6 +37,14 @@ class StatsAccumulator:
         for i, k in enumerate(STAT_KEYS):
             self.vec[i] += row[k]
 
+    def add_batch_device(self, sse, values_per_image: int, bits: float, pixels: float, nbytes: float = 0.0,
+                         seconds: float = 0.0, side_bits: float = 0.0, msssim=None, reset: bool = False):
+        """The same sums for a whole batch without a device-to-host copy: `sse` (and `msssim`) are float64 [B] tensors
+        on the GPU (ops.clamp_sse_per_image, pt_ms_ssim.ms_ssim(size_average=False)); PSNR and MS-SSIM dB are formed
+        per image on the device.  The accumulator's vector must live on that GPU."""
+        from . import ops
+        ops.stats_accumulate(self.vec, sse, values_per_image, bits, pixels, nbytes, seconds, side_bits, msssim, reset)
+
     def all_reduce(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

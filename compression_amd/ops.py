@@ -137,6 +137,38 @@ def clamp_sse(recon: torch.Tensor, target: Optional[torch.Tensor]):
     return xhat, sse
 
 
+def clamp_sse_per_image(recon: torch.Tensor, target: torch.Tensor, score_clamped: bool = True):
+    """-> (clamp(recon,0,1), float64[B] sum of squared errors of every image of the batch, taken on the clamped
+    values (what the test harness' PSNR sees) or, with score_clamped=False, on the raw reconstruction)."""
+    _dev(recon, torch.float32, "recon"); _dev(target, torch.float32, "target")
+    if target.shape != recon.shape:
+        raise MpcError("clamp_sse_per_image: shape mismatch")
+    B = recon.shape[0]
+    xhat = torch.empty_like(recon)
+    sse = torch.empty(B, dtype=torch.float64, device=recon.device)
+    with _timed("clamp_sse", bytes=3.0 * recon.numel() * 4):
+        context_for(recon.device).call("mpc_clamp_sse_batched", ptr(recon), ptr(target), B, recon.numel() // B,
+                                       int(score_clamped), ptr(xhat), ptr(sse))
+    return xhat, sse
+
+
+def stats_accumulate(vec: torch.Tensor, sse: torch.Tensor, values_per_image: int, bits: float, pixels: float, nbytes: float,
+                     seconds: float = 0.0, side_bits: float = 0.0, msssim: Optional[torch.Tensor] = None,
+                     reset: bool = False) -> None:
+    """Adds one batch to the 16-double statistics vector `vec` on the device (layout: include/mpc.h,
+    mpc_stats_accumulate), or with `reset` makes it this batch's sums.  sse / msssim: float64 [B] device tensors."""
+    _dev(vec, torch.float64, "vec"); _dev(sse, torch.float64, "sse")
+    if vec.numel() < 16:
+        raise MpcError("stats_accumulate: vec must hold 16 doubles")
+    if msssim is not None:
+        _dev(msssim, torch.float64, "msssim")
+        if msssim.numel() != sse.numel():
+            raise MpcError("stats_accumulate: msssim and sse must have one entry per image")
+    hs = (ctypes.c_double * 5)(float(bits), float(pixels), float(nbytes), float(seconds), float(side_bits))
+    context_for(vec.device).call("mpc_stats_accumulate", ptr(sse), ptr(msssim), sse.numel(), int(values_per_image), hs,
+                                 int(reset), ptr(vec))
+
+
 # ---- learned CDF tables ------------------------------------------------------------------------
 def _param_array(params: Sequence[torch.Tensor], n_rows: int):
     if len(params) != 11:
@@ -209,13 +241,16 @@ def prior_argmin(sym: torch.Tensor, lut: torch.Tensor, want_total: bool = False)
     return idx, minbits, total
 
 
-def gather_cdf(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    """table int16 [K,M,L], idx int32 [n_loc] -> int16 [n_loc, M, L]."""
+def gather_cdf(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """table int16 [K,M,L], idx int32 [n_loc] -> int16 [n_loc, M, L] (written into `out` when given)."""
     _dev(table, torch.int16, "table")
     _dev(idx, torch.int32, "idx")
     K, M, L = table.shape
     n_loc = idx.numel()
-    out = torch.empty((n_loc, M, L), dtype=torch.int16, device=table.device)
+    if out is None:
+        out = torch.empty((n_loc, M, L), dtype=torch.int16, device=table.device)
+    elif _dev(out, torch.int16, "out").numel() != n_loc * M * L:
+        raise MpcError("gather_cdf: out has the wrong size")
     with _timed("gather_cdf", bytes=float(n_loc) * M * L * 2):
         context_for(table.device).call("mpc_gather_cdf", ptr(table), K, M, L, ptr(idx), n_loc, ptr(out))
     return out

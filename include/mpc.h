@@ -77,6 +77,12 @@ int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev);
 int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t n, float *xhat,
                   double *sse_dev);
 
+/* The same for n_images images of n_per_image elements each, with one sum per image: sse_dev[i].  score_clamped != 0
+ * takes the error on the clamped value: the per-image MSE / PSNR that the reference's test harness logs from
+ * "reconstructed_image" (src/compression/tests.py:393-398); 0 takes it on the raw reconstruction (the visual loss). */
+int mpc_clamp_sse_batched(mpc_ctx *ctx, const float *recon, const float *target, int n_images,
+                          int64_t n_per_image, int score_clamped, float *xhat, double *sse_dev);
+
 /* ---- image-quality statistics of the reference's test harness (src/compression/tests.py:393-418) ------------- */
 /* Sums over the valid region ((H-win_size+1) x (W-win_size+1)) of the SSIM map and of the contrast-structure map
  * of every plane of x and y ([planes][H][W] fp32, planes = batch*channels), with the separable window `window`
@@ -87,6 +93,17 @@ int mpc_ssim_stats(mpc_ctx *ctx, const float *x, const float *y, int planes, int
 /* F.avg_pool2d(kernel_size=2, padding=(H%2, W%2)) between the MS-SSIM scales (pt_ms_ssim.py:205-207):
  * out [planes][Ho][Wo], Ho = (H + 2*(H%2) - 2)/2 + 1. */
 int mpc_avg_pool2(mpc_ctx *ctx, const float *in, int64_t planes, int H, int W, float *out);
+
+/* Adds one batch to the running sums that the reference's test harness keeps per evaluated directory
+ * (src/compression/tests.py:439-460) and that the multi-GPU driver all-reduces.  vec_dev: 16 doubles on the device,
+ * [0] bits, [1] pixels, [2] squared error, [3] sum of per-image PSNR, [4] images, [5] bytes, [6] seconds,
+ * [7] side-string bits, [8] sum of per-image MS-SSIM, [9] sum of per-image MS-SSIM in dB, [10..15] unused.
+ * sse_dev[i]: squared error of image i over values_per_image (= 3*H*W) values (mpc_clamp_sse_batched);
+ * msssim_dev[i] (may be NULL): its MS-SSIM; host_sums (host array) = {bits, pixels, bytes, seconds, side_bits} of the
+ * batch; reset != 0 starts the sums from zero instead of adding to vec_dev.  PSNR = 10 log10(1 / mse), MS-SSIM dB =
+ * -10 log10(1 - msssim) (tests.py:393-412). */
+int mpc_stats_accumulate(mpc_ctx *ctx, const double *sse_dev, const double *msssim_dev, int n_images,
+                         int64_t values_per_image, const double host_sums[5], int reset, double *vec_dev);
 
 /* ---- learned CDF tables -------------------------------------------------------------------- */
 /* Float CDF table of a (multi-head) factorised prior evaluated at targets first_target + s, s < L:
