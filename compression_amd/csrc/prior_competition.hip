@@ -13,8 +13,12 @@
 // totals are therefore bit-identical to the reference's, and so is the argmin.
 //
 // gather_cdf: cdf[loc][c][:] = table[idx[loc]][c][:].  table[k] is one contiguous M*L*2-byte block, so
-// a location's rows are a straight block copy: one workgroup per location, 16-byte loads from the
-// L2-resident table and 16-byte non-temporal stores.  Pure HBM-write streaming: 2*L bytes per symbol.
+// a location's rows are a straight block copy.  Pure HBM-write streaming: 2*L bytes per symbol; the only reads
+// are the table's.  The locations are first ordered by prior index (a counting sort, three small launches), then
+// one 1024-thread workgroup per location, in that order, loads the prior's block into registers and writes it
+// with 16-byte non-temporal stores: workgroups that run together copy the same few priors, so the table reads
+// are L2 hits instead of 128 KB per location from beyond L2 (measured at 36 864 locations: 6.0 TB/s against
+// 4.5 TB/s for the unordered copy; a device memset reaches 6.4 TB/s).
 #include "mpc_internal.h"
 
 namespace {
@@ -108,13 +112,100 @@ __global__ __launch_bounds__(256) void prior_argmin_kernel(const int16_t *__rest
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int SORT_MAX_K = 4096;           // priors the counting sort handles (LDS histogram)
+constexpr int SORT_CHUNK = 1024;           // locations per workgroup of the sort kernels
+constexpr int GATHER_T = 1024;             // threads of the copy workgroup
+
+__device__ __forceinline__ int clamp_prior(int k, int K) { return k < 0 ? 0 : (k >= K ? K - 1 : k); }
+
+// counts[k] = number of locations with prior k
+__global__ __launch_bounds__(SORT_CHUNK) void prior_histogram_kernel(const int32_t *__restrict__ idx, int64_t n_loc, int K,
+                                                                      int32_t *__restrict__ counts) {
+    extern __shared__ int32_t lds_cnt[];
+    for (int k = threadIdx.x; k < K; k += SORT_CHUNK) lds_cnt[k] = 0;
+    __syncthreads();
+    const int64_t loc = (int64_t)blockIdx.x * SORT_CHUNK + threadIdx.x;
+    if (loc < n_loc) atomicAdd(&lds_cnt[clamp_prior(idx[loc], K)], 1);
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += SORT_CHUNK)
+        if (lds_cnt[k]) atomicAdd(&counts[k], lds_cnt[k]);
+}
+
+// cursor[k] = number of locations with a prior below k (one workgroup)
+__global__ __launch_bounds__(256) void prior_scan_kernel(const int32_t *__restrict__ counts, int K, int32_t *__restrict__ cursor) {
+    __shared__ int32_t part[256];
+    const int t = threadIdx.x, per = (K + 255) / 256;
+    int32_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        int k = t * per + j;
+        if (k < K) sum += counts[k];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        int32_t a = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    int32_t run = part[t] - sum;
+    for (int j = 0; j < per; ++j) {
+        int k = t * per + j;
+        if (k < K) {
+            cursor[k] = run;
+            run += counts[k];
+        }
+    }
+}
+
+// order[...] = the locations grouped by prior (any order inside a group)
+__global__ __launch_bounds__(SORT_CHUNK) void prior_scatter_kernel(const int32_t *__restrict__ idx, int64_t n_loc, int K,
+                                                                    int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+    extern __shared__ int32_t lds[];                       // [K] counts of this chunk, then [K] their bases
+    int32_t *cnt = lds, *base = lds + K;
+    for (int k = threadIdx.x; k < K; k += SORT_CHUNK) cnt[k] = 0;
+    __syncthreads();
+    const int64_t loc = (int64_t)blockIdx.x * SORT_CHUNK + threadIdx.x;
+    int k = 0, rank = 0;
+    if (loc < n_loc) {
+        k = clamp_prior(idx[loc], K);
+        rank = atomicAdd(&cnt[k], 1);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < K; q += SORT_CHUNK)
+        if (cnt[q]) base[q] = atomicAdd(&cursor[q], cnt[q]);
+    __syncthreads();
+    if (loc < n_loc) order[base[k] + rank] = (int32_t)loc;
+}
+
+// one workgroup per location, taken in prior order; R 16-byte vectors per thread
+__global__ __launch_bounds__(GATHER_T) void gather_cdf_sorted_kernel(const u32x4 *__restrict__ table, int64_t vec_per_prior,
+                                                                      const int32_t *__restrict__ idx, const int32_t *__restrict__ order,
+                                                                      int K, u32x4 *__restrict__ out) {
+    const int64_t loc = order[blockIdx.x];
+    const u32x4 *src = table + (int64_t)clamp_prior(idx[loc], K) * vec_per_prior;
+    u32x4 *dst = out + loc * vec_per_prior;
+    for (int64_t i0 = 0; i0 < vec_per_prior; i0 += 12 * GATHER_T) {
+        u32x4 r[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int64_t i = i0 + (int64_t)j * GATHER_T + threadIdx.x;
+            if (i < vec_per_prior) r[j] = src[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int64_t i = i0 + (int64_t)j * GATHER_T + threadIdx.x;
+            if (i < vec_per_prior) __builtin_nontemporal_store(r[j], dst + i);
+        }
+    }
+}
+
+// unordered form (more priors than the sort handles): one 256-thread workgroup per location
 __global__ __launch_bounds__(256) void gather_cdf_vec_kernel(const u32x4 *__restrict__ table, int64_t vec_per_prior,
                                                               const int32_t *__restrict__ idx, int K,
                                                               u32x4 *__restrict__ out) {
     const int64_t loc = blockIdx.x;
-    int k = idx[loc];
-    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
-    const u32x4 *src = table + (int64_t)k * vec_per_prior;
+    const u32x4 *src = table + (int64_t)clamp_prior(idx[loc], K) * vec_per_prior;
     u32x4 *dst = out + loc * vec_per_prior;
     int64_t i = threadIdx.x;
     for (; i + 3 * 256 < vec_per_prior; i += 4 * 256) {
@@ -131,9 +222,7 @@ __global__ __launch_bounds__(256) void gather_cdf_scalar_kernel(const int16_t *_
                                                                  const int32_t *__restrict__ idx, int K,
                                                                  int16_t *__restrict__ out) {
     const int64_t loc = blockIdx.x;
-    int k = idx[loc];
-    k = k < 0 ? 0 : (k >= K ? K - 1 : k);
-    const int16_t *src = table + (int64_t)k * per_prior;
+    const int16_t *src = table + (int64_t)clamp_prior(idx[loc], K) * per_prior;
     int16_t *dst = out + loc * per_prior;
     for (int64_t i = threadIdx.x; i < per_prior; i += 256) dst[i] = src[i];
 }
@@ -161,7 +250,20 @@ int mpc_gather_cdf(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, cons
                 "gather_cdf: bad arguments");
     int64_t per_prior = (int64_t)M * L;
     bool vec_ok = (per_prior * 2) % 16 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0;
-    if (vec_ok) {
+    if (vec_ok && K <= SORT_MAX_K) {
+        // scratch: order[n_loc], counts[K], cursor[K]
+        int32_t *order = (int32_t *)mpc_ctx_scratch(ctx, sizeof(int32_t) * ((size_t)n_loc + 2 * (size_t)K));
+        if (!order) return MPC_ENOMEM;
+        int32_t *counts = order + n_loc, *cursor = counts + K;
+        const unsigned chunks = (unsigned)mpc_cdiv(n_loc, SORT_CHUNK);
+        MPC_HIP(ctx, hipMemsetAsync(counts, 0, sizeof(int32_t) * K, ctx->stream));
+        prior_histogram_kernel<<<dim3(chunks), dim3(SORT_CHUNK), sizeof(int32_t) * K, ctx->stream>>>(idx, n_loc, K, counts);
+        prior_scan_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(counts, K, cursor);
+        prior_scatter_kernel<<<dim3(chunks), dim3(SORT_CHUNK), sizeof(int32_t) * 2 * K, ctx->stream>>>(idx, n_loc, K, cursor, order);
+        gather_cdf_sorted_kernel<<<dim3((unsigned)n_loc), dim3(GATHER_T), 0, ctx->stream>>>(
+            (const u32x4 *)table, per_prior * 2 / 16, idx, order, K, (u32x4 *)out);
+        mpc_ctx_scratch_release(ctx);
+    } else if (vec_ok) {
         gather_cdf_vec_kernel<<<dim3((unsigned)n_loc), dim3(256), 0, ctx->stream>>>(
             (const u32x4 *)table, per_prior * 2 / 16, idx, K, (u32x4 *)out);
     } else {

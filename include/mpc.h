@@ -141,7 +141,8 @@ int mpc_prior_argmin(mpc_ctx *ctx, const int16_t *sym, int64_t n_loc, int M, int
 /* ---- per-symbol CDF rows ("CDF build") ------------------------------------------------------ */
 /* out[loc][c][:] = table[idx[loc]][c][:]   (int16 [n_loc][M][L]).  manynets_compressor.py:252-262,
  * :317-327, :707-710.  Only parity tests and the reference-style torchac hand-off need the
- * materialised rows; the rANS coder below reads the table directly. */
+ * materialised rows; the rANS coder below reads the table directly.  Orders the locations by prior index first
+ * (4*(n_loc + 2K) bytes of context scratch), so that concurrent copies read the same table blocks. */
 int mpc_gather_cdf(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                    int64_t n_loc, int16_t *out);
 

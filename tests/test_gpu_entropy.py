@@ -138,6 +138,12 @@ def test_gather_cdf_rows(dev, ops, priors):
     want = O.gather_cdf(table, idx)
     got = ops.gather_cdf(table.to(dev), idx.to(dev)).cpu()
     assert torch.equal(got, want)
+    # many locations (several chunks of the prior-ordering pass), uneven prior usage, one prior only
+    g3 = torch.Generator().manual_seed(4)
+    big = torch.randint(0, K, (3001,), generator=g3, dtype=torch.int32)
+    big[torch.rand(3001, generator=g3) < 0.7] = 5
+    for case in (big, torch.full((1500,), K - 1, dtype=torch.int32)):
+        assert torch.equal(ops.gather_cdf(table.to(dev), case.to(dev)).cpu(), O.gather_cdf(table, case))
     # a shape whose per-prior block is not a multiple of 16 bytes takes the scalar path
     t2 = table[:, :3, :].contiguous()
     assert torch.equal(ops.gather_cdf(t2.to(dev), idx.to(dev)).cpu(), O.gather_cdf(t2, idx))
