@@ -94,6 +94,17 @@ class Analysis_net(_FusedNet):
             t = l3(l2(l1(x4)))
         return l4(t, round_out=round_out, keep_unrounded=keep_unrounded)
 
+    def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False):
+        """x4 -> (round(y) | None, int16 symbols NHWC, clamped count): quantisation and symbolisation run in the last
+        layer's epilogue."""
+        l1, l2, l3, l4 = self.layers()
+        if self.precision == "f16x3":
+            self._check_split_range()
+            t = l3(l2(l1(x4, out_split=True), out_split=True), out_split=True)
+        else:
+            t = l3(l2(l1(x4)))
+        return l4.forward_symbols(t, min_feat, n_sym_values, n_clamped, keep_rounded)
+
     def _check_split_range(self):
         """|GDN output_i| <= 1/sqrt(gamma_eff_ii); the split format holds |v| < 255.9."""
         fp = self._fused_fp
@@ -134,9 +145,13 @@ class Synthesis_net(_FusedNet):
         """y: NHWC fp32 latent -> NCHW fp32 image (unclamped).  With precision "fp16" (default) the four layers
         run on fp16-operand MFMA with fp16 activations: x_hat stays within 1e-2 of the fp32 result."""
         l1, l2, l3, l4 = self.layers()
-        if self.precision == "fp16":
+        if self.precision == "fp16" and y.dtype != torch.float16:
             y = ops.f32_to_f16(y)
         return l4(l3(l2(l1(y))), nchw_out=True)
+
+    def latent_from_symbols(self, sym, min_feat, q_intv):
+        """int16 symbols NHWC -> the latent in the type this network's first layer takes."""
+        return ops.symbols_to_latent_f16(sym, min_feat, q_intv) if self.precision == "fp16" else ops.symbols_to_latent(sym, min_feat, q_intv)
 
     def forward(self, x):
         return self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous()))

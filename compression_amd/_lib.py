@@ -44,6 +44,8 @@ SIGNATURES = {
     "mpc_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mpc_latent_to_symbols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_symbols_to_latent": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "mpc_symbols_to_latent_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "mpc_download_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t]),
     "mpc_sum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_clamp_sse": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mpc_clamp_sse_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
@@ -60,6 +62,9 @@ SIGNATURES = {
     "mpc_rans_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "mpc_rans_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,
                                 c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mpc_rans_auto_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
+    "mpc_rans_encode_auto": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_double,
+                                     c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mpc_rans_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
                                 c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mpc_rans_decode_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
@@ -68,6 +73,7 @@ SIGNATURES = {
     "mpc_conv_destroy": (c_int, [c_void_p]),
     "mpc_conv_out_hw": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "mpc_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mpc_conv_forward_symbols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mpc_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_laplace_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -128,6 +128,12 @@ __global__ void symbols_to_latent_kernel(const int16_t *__restrict__ sym, int64_
     if (i < n) latent[i] = (float)((int)sym[i] * q_intv + min_feat);
 }
 
+__global__ void symbols_to_latent_f16_kernel(const int16_t *__restrict__ sym, int64_t n, int min_feat, int q_intv,
+                                             _Float16 *__restrict__ latent) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) latent[i] = (_Float16)fminf(fmaxf((float)((int)sym[i] * q_intv + min_feat), -65504.0f), 65504.0f);
+}
+
 // Double-precision sum: per-thread strided partial, wave shuffle reduce, one atomic per wave.
 __global__ void sum_f32_kernel(const float *__restrict__ x, int64_t n, double *__restrict__ out) {
     double acc = 0.0;
@@ -277,6 +283,23 @@ int mpc_symbols_to_latent(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_f
     MPC_REQUIRE(ctx, latent && sym && n > 0, "symbols_to_latent: bad arguments");
     symbols_to_latent_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(sym, n, min_feat, q_intv, latent);
     MPC_CHECK_LAUNCH(ctx, "symbols_to_latent");
+    return MPC_OK;
+}
+
+int mpc_symbols_to_latent_f16(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_feat, int q_intv, void *latent_f16) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, latent_f16 && sym && n > 0, "symbols_to_latent_f16: bad arguments");
+    symbols_to_latent_f16_kernel<<<dim3((unsigned)mpc_cdiv(n, 256)), dim3(256), 0, ctx->stream>>>(sym, n, min_feat, q_intv, (_Float16 *)latent_f16);
+    MPC_CHECK_LAUNCH(ctx, "symbols_to_latent_f16");
+    return MPC_OK;
+}
+
+int mpc_download_rows(mpc_ctx *ctx, const void *src_dev, size_t src_pitch, size_t width, size_t rows, void *dst_host,
+                      size_t dst_pitch) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, src_dev && dst_host && width > 0 && rows > 0 && width <= src_pitch && width <= dst_pitch,
+                "download_rows: bad arguments");
+    MPC_HIP(ctx, hipMemcpy2DAsync(dst_host, dst_pitch, src_dev, src_pitch, width, rows, hipMemcpyDeviceToHost, ctx->stream));
     return MPC_OK;
 }
 

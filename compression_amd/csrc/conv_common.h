@@ -58,8 +58,31 @@ struct Params {
     const void *gamma_x3; // f16x3 GDN: fp16 hi/lo gamma in MFMA operand order (null -> exact f32 GDN)
     float y2_scale;       // f16x3 GDN: power-of-two scale of y^2 (0 -> exact f32 GDN)
     float gdn_unscale;    // 1 / (gamma scale * y2_scale)
+    int16_t *out_sym;     // plain epilogue: int16 symbols of rint(out) (null: none), NHWC like out_round
+    float sym_min_feat;   // symbol = rint(out) - sym_min_feat, clamped to [0, sym_max]
+    int sym_max;
+    int *n_clamped;       // number of symbols that had to be clamped (may be null)
     Phase ph[MAX_PHASES];
 };
+
+#if defined(__HIPCC__)
+// Four consecutive channels of one pixel as int16 symbols (8 bytes): ((y_hat - min_feat) / 1).round().short() of the
+// reference (src/compression/models/manynets_compressor.py:264-269) with q_intv = 1; out-of-range values are clamped
+// and counted so that the caller can widen its tables as the reference does (:212-227).
+__device__ __forceinline__ void store_symbols4(const Params &p, int64_t elem, const float (&rounded)[4], int &clamped) {
+    typedef short short4_t __attribute__((ext_vector_type(4)));
+    short4_t s4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v = rounded[t] - p.sym_min_feat;
+        int s = (int)v;
+        if (!(v >= 0.0f)) { s = 0; ++clamped; }
+        if (v > (float)p.sym_max) { s = p.sym_max; ++clamped; }
+        s4[t] = (short)s;
+    }
+    *(short4_t *)(p.out_sym + elem) = s4;
+}
+#endif
 
 
 // ---------------------------------------------------------------------------------------------

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
         const bool nchw = (p.flags & MPC_OUT_NCHW) != 0;
         const bool clamp01 = (p.flags & MPC_OUT_CLAMP01) != 0;
         const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+        int sym_clamped = 0;
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -271,8 +272,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const Params p) {
                 } else {
                     if (out_f) *(float4 *)(out_f + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
                     if (p.out_round) *(float4 *)(p.out_round + opix * p.cout + c0) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+                    if (p.out_sym) store_symbols4(p, opix * p.cout + c0, orr, sym_clamped);
                 }
             }
+        if (sym_clamped && p.n_clamped) atomicAdd(p.n_clamped, sym_clamped);
     }
 }
 
@@ -684,14 +687,22 @@ int mpc_conv_out_hw(const mpc_conv *c, int H, int W, int *Ho, int *Wo) {
     return MPC_OK;
 }
 
-int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
-                     float *out_round) {
-    MPC_ENTER(ctx);
+}  // extern "C"
+
+// Body of mpc_conv_forward and mpc_conv_forward_symbols (sym == nullptr: no symbol output).
+static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
+                             float *out_round, int16_t *sym, int min_feat, int n_sym_values, int32_t *n_clamped_dev) {
     MPC_REQUIRE(ctx, c && in && B > 0 && H > 0 && W > 0, "conv_forward: bad arguments");
     MPC_REQUIRE(ctx, c->device == ctx->device, "conv_forward: layer was created on another device");
     const mpc_conv_desc &d = c->desc;
     const bool want_round = (flags & MPC_OUT_ROUND) != 0;
-    MPC_REQUIRE(ctx, want_round ? out_round != nullptr : out != nullptr, "conv_forward: output pointer is NULL");
+    MPC_REQUIRE(ctx, sym || (want_round ? out_round != nullptr : out != nullptr), "conv_forward: output pointer is NULL");
+    if (sym) {
+        MPC_REQUIRE(ctx, d.act == MPC_ACT_NONE && !c->f16 && !c->stacked && !(flags & (MPC_OUT_NCHW | MPC_OUT_CLAMP01 | MPC_OUT_SPLIT)),
+                    "conv_forward_symbols: needs a layer without activation on the f32 or f16x3 path, NHWC output");
+        MPC_REQUIRE(ctx, n_sym_values > 0 && n_sym_values <= 32767, "conv_forward_symbols: bad symbol range");
+        if (n_clamped_dev) MPC_HIP(ctx, hipMemsetAsync(n_clamped_dev, 0, sizeof(int32_t), ctx->stream));
+    }
     const bool gdn = d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN;
     MPC_REQUIRE(ctx, !(gdn && (flags & (MPC_OUT_ROUND | MPC_OUT_NCHW | MPC_OUT_CLAMP01))), "conv_forward: GDN layers write NHWC only");
     MPC_REQUIRE(ctx, !(c->stacked && want_round), "conv_forward: rounding is not available on the small-cout layer");
@@ -701,6 +712,7 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
     int Ho, Wo;
     mpc_conv_out_hw(c, H, W, &Ho, &Wo);
     p.in = in; p.out = out; p.out_round = want_round ? out_round : nullptr;
+    p.out_sym = sym; p.sym_min_feat = (float)min_feat; p.sym_max = n_sym_values - 1; p.n_clamped = n_clamped_dev;
     p.wpk = c->wpk; p.bias = c->bias; p.beta = c->beta; p.gamma = c->gamma; p.taps = c->taps;
     p.B = B; p.Hi = H; p.Wi = W; p.Cs = c->cin4 ? 4 : d.cin;
     p.Ho = Ho; p.Wo = Wo; p.sy = c->sy; p.sx = c->sx; p.my = c->my; p.mx = c->mx;
@@ -750,6 +762,22 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
         if (c->nf == 6) return launch<6, true, EPI_PLAIN>(ctx, p, np, ng);
     }
     MPC_FAIL(ctx, MPC_EINVAL, "conv_forward: unsupported layer shape (cout/32 = %d, cin4 = %d, gdn = %d)", c->nf, (int)c->cin4, (int)gdn);
+}
+
+extern "C" {
+
+int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
+                     float *out_round) {
+    MPC_ENTER(ctx);
+    return conv_forward_impl(ctx, c, in, B, H, W, flags, out, out_round, nullptr, 0, 1, nullptr);
+}
+
+int mpc_conv_forward_symbols(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int min_feat,
+                             int n_sym_values, float *out_round, int16_t *sym, int32_t *n_clamped_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, sym != nullptr, "conv_forward_symbols: sym is NULL");
+    return conv_forward_impl(ctx, c, in, B, H, W, out_round ? MPC_OUT_ROUND : 0, nullptr, out_round, sym, min_feat,
+                             n_sym_values, n_clamped_dev);
 }
 
 }  // extern "C"

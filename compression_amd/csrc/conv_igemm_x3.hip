@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
     } else {
         if (!pvalid) return;
         float *out_f = (float *)p.out;
+        int sym_clamped = 0;
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -373,8 +374,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
                 } else {
                     if (out_f) *(float4 *)(out_f + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
                     if (p.out_round) *(float4 *)(p.out_round + opix * p.cout + c0) = make_float4(orr[0], orr[1], orr[2], orr[3]);
+                    if (p.out_sym) store_symbols4(p, opix * p.cout + c0, orr, sym_clamped);
                 }
             }
+        if (sym_clamped && p.n_clamped) atomicAdd(p.n_clamped, sym_clamped);
     }
 }
 

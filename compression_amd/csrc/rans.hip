@@ -42,11 +42,54 @@ struct Geometry {
     uint32_t cap_words;     // sps + 2
 };
 
+// Stream geometry chosen on the device (mpc_rans_encode_auto): ov = {n_streams, locs_per_stream} replaces the
+// host's values (which then only size the launch: grids cover the largest geometry, surplus threads leave).
+__device__ __forceinline__ Geometry resolve(Geometry g, const int32_t *__restrict__ ov) {
+    if (ov) {
+        g.n_streams = ov[0];
+        g.locs_per_stream = ov[1];
+        g.sps = (uint32_t)ov[1] * (uint32_t)g.M;
+        g.cap_words = g.sps + 2;
+    }
+    return g;
+}
+
+// One workgroup: est = sum(minbits) / 8 / n_images bytes per image, then the stream count that keeps the container's
+// per-stream overhead (6 bytes) within `budget` of it -- the rule of ops.choose_streams, evaluated in double.
+__global__ __launch_bounds__(1024) void choose_geometry_kernel(const float *__restrict__ minbits, int64_t n, int n_images,
+                                                               int64_t n_loc, int M, double budget, int max_streams,
+                                                               int32_t *__restrict__ ov) {
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += (double)minbits[i];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int w = 0; w < 16; ++w) total += part[w];
+        const double est = total / 8.0 / (double)n_images;
+        const int64_t per = 65533 / M > 0 ? 65533 / M : 1;
+        const int64_t min_streams = (n_loc + per - 1) / per;
+        double w = est * budget - 16.0;
+        int64_t want = (w > 0.0) ? (int64_t)floor(w / 6.0) : 0;       // NaN compares false: no extra streams
+        int64_t ns = want < max_streams ? want : max_streams;
+        if (ns > n_loc) ns = n_loc;
+        if (ns < min_streams) ns = min_streams;
+        if (ns < 1) ns = 1;
+        const int64_t lps = (n_loc + ns - 1) / ns;
+        ns = (n_loc + lps - 1) / lps;                                   // drop streams that would be empty
+        ov[0] = (int32_t)ns;
+        ov[1] = (int32_t)lps;
+    }
+}
+
 __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const uint16_t *__restrict__ table,
                                                              const int32_t *__restrict__ idx,
                                                              const int16_t *__restrict__ sym,
                                                              uint32_t *__restrict__ params,
-                                                             int32_t *__restrict__ status) {
+                                                             int32_t *__restrict__ status, const int32_t *__restrict__ ov) {
+    g = resolve(g, ov);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)g.n_images * g.n_symbols;
     if (i >= total) return;
@@ -72,7 +115,8 @@ __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const ui
 
 __global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const uint32_t *__restrict__ params,
                                                              uint16_t *__restrict__ scratch,
-                                                             uint32_t *__restrict__ lens) {
+                                                             uint32_t *__restrict__ lens, const int32_t *__restrict__ ov) {
+    g = resolve(g, ov);
     int64_t G = (int64_t)g.n_images * g.n_streams;
     int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= G) return;
@@ -122,7 +166,8 @@ __global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const ui
 __global__ __launch_bounds__(256) void header_kernel(Geometry g, const uint32_t *__restrict__ lens,
                                                       uint32_t *__restrict__ offs, uint8_t *__restrict__ out,
                                                       size_t out_stride, uint64_t *__restrict__ nbytes,
-                                                      int32_t *__restrict__ status) {
+                                                      int32_t *__restrict__ status, const int32_t *__restrict__ ov) {
+    g = resolve(g, ov);
     __shared__ uint32_t part[256];
     __shared__ uint32_t base_sh;
     const int img = blockIdx.x, t = threadIdx.x;
@@ -168,8 +213,10 @@ __global__ __launch_bounds__(256) void copy_streams_kernel(Geometry g, const uin
                                                             const uint32_t *__restrict__ lens,
                                                             const uint32_t *__restrict__ offs,
                                                             uint8_t *__restrict__ out, size_t out_stride,
-                                                            const uint64_t *__restrict__ nbytes) {
+                                                            const uint64_t *__restrict__ nbytes, const int32_t *__restrict__ ov) {
+    g = resolve(g, ov);
     int64_t gid = blockIdx.x;
+    if (gid >= (int64_t)g.n_images * g.n_streams) return;   // grid sized for the largest geometry
     int img = (int)(gid / g.n_streams);
     if (nbytes[img] > out_stride) return;
     uint32_t nw = lens[gid];
@@ -590,6 +637,51 @@ size_t mpc_rans_workspace_bytes(int n_images, int64_t n_loc, int M, int n_stream
     return carve(nullptr, n_images, n_loc, M, n_streams, lps).bytes;
 }
 
+}  // extern "C"
+
+// Launches of both encode entry points.  g holds the geometry the grids are sized for; ov (device, may be null)
+// the geometry the kernels actually use.
+static int rans_encode_launch(mpc_ctx *ctx, const Geometry &g, const int16_t *table, const int32_t *idx, const int16_t *sym,
+                              const Workspace &w, uint8_t *out, size_t out_stride, uint64_t *nbytes_dev, int32_t *status_dev,
+                              const int32_t *ov) {
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    const int64_t total = (int64_t)g.n_images * g.n_symbols;
+    MPC_REQUIRE(ctx, mpc_cdiv(total, 256) < (1ll << 31), "rans_encode: too many symbols in one call");
+    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
+    symbol_params_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(
+        g, (const uint16_t *)table, idx, sym, w.params, status_dev, ov);
+    MPC_CHECK_LAUNCH(ctx, "rans symbol_params");
+    encode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, 64)), dim3(64), 0, ctx->stream>>>(g, w.params, w.scratch, w.lens, ov);
+    MPC_CHECK_LAUNCH(ctx, "rans encode_streams");
+    header_kernel<<<dim3((unsigned)g.n_images), dim3(256), 0, ctx->stream>>>(g, w.lens, w.offs, out, out_stride, nbytes_dev, status_dev, ov);
+    MPC_CHECK_LAUNCH(ctx, "rans header");
+    copy_streams_kernel<<<dim3((unsigned)G), dim3(256), 0, ctx->stream>>>(g, w.scratch, w.lens, w.offs, out, out_stride, nbytes_dev, ov);
+    MPC_CHECK_LAUNCH(ctx, "rans copy_streams");
+    return MPC_OK;
+}
+
+// Workspace for any geometry with at most max_streams streams: n_streams * locs_per_stream < n_loc + n_streams.
+static Workspace carve_max(void *base, int n_images, int64_t n_loc, int M, int max_streams) {
+    Workspace w;
+    const size_t G = (size_t)n_images * max_streams;
+    const size_t sym_slots = (size_t)n_images * ((size_t)n_loc + max_streams) * M;     // >= G' * sps for every geometry
+    size_t off = 0;
+    uint8_t *p = (uint8_t *)base;
+    w.params = (uint32_t *)(p + off); off += align256(sym_slots * 4);
+    w.scratch = (uint16_t *)(p + off); off += align256((sym_slots + 2 * G) * 2);
+    w.lens = (uint32_t *)(p + off); off += align256(G * 4);
+    w.offs = (uint32_t *)(p + off); off += align256(G * 4);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" {
+
+size_t mpc_rans_auto_workspace_bytes(int n_images, int64_t n_loc, int M, int max_streams) {
+    if (n_images <= 0 || n_loc <= 0 || M <= 0 || max_streams <= 0) return 0;
+    return carve_max(nullptr, n_images, n_loc, M, max_streams).bytes;
+}
+
 int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const int16_t *sym,
                     int n_images, int64_t n_loc, int n_streams, int locs_per_stream, void *workspace,
                     size_t workspace_bytes, uint8_t *out, size_t out_stride, uint64_t *nbytes_dev,
@@ -605,21 +697,38 @@ int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     Workspace w = carve(workspace, n_images, n_loc, M, n_streams, locs_per_stream);
     if (w.bytes > workspace_bytes) MPC_FAIL(ctx, MPC_ENOMEM, "rans_encode: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
     MPC_REQUIRE(ctx, out_stride >= 16 + 2 * (size_t)n_streams, "rans_encode: out_stride smaller than the header");
-    int64_t G = (int64_t)n_images * n_streams;
-    int64_t total = (int64_t)n_images * g.n_symbols;
-    MPC_REQUIRE(ctx, mpc_cdiv(total, 256) < (1ll << 31), "rans_encode: too many symbols in one call");
-    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * n_images, ctx->stream));
-    symbol_params_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(
-        g, (const uint16_t *)table, idx, sym, w.params, status_dev);
-    MPC_CHECK_LAUNCH(ctx, "rans symbol_params");
-    encode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, 64)), dim3(64), 0, ctx->stream>>>(g, w.params, w.scratch, w.lens);
-    MPC_CHECK_LAUNCH(ctx, "rans encode_streams");
-    header_kernel<<<dim3((unsigned)n_images), dim3(256), 0, ctx->stream>>>(g, w.lens, w.offs, out, out_stride, nbytes_dev, status_dev);
-    MPC_CHECK_LAUNCH(ctx, "rans header");
-    copy_streams_kernel<<<dim3((unsigned)G), dim3(256), 0, ctx->stream>>>(g, w.scratch, w.lens, w.offs, out, out_stride, nbytes_dev);
-    MPC_CHECK_LAUNCH(ctx, "rans copy_streams");
-    return MPC_OK;
+    return rans_encode_launch(ctx, g, table, idx, sym, w, out, out_stride, nbytes_dev, status_dev, nullptr);
 }
+
+int mpc_rans_encode_auto(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const int16_t *sym,
+                         const float *minbits, int n_images, int64_t n_loc, double budget, int max_streams,
+                         void *workspace, size_t workspace_bytes, uint8_t *out, size_t out_stride, uint64_t *nbytes_dev,
+                         int32_t *status_dev, int32_t *geometry_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, table && idx && sym && minbits && workspace && out && nbytes_dev && status_dev && geometry_dev,
+                "rans_encode_auto: NULL argument");
+    MPC_REQUIRE(ctx, max_streams > 0 && budget >= 0.0, "rans_encode_auto: bad budget / max_streams");
+    if ((int64_t)max_streams > n_loc) max_streams = (int)n_loc;
+    // the shortest streams any choice can have: every location count per stream from 1 up is legal for the grids below
+    const int64_t per = 65533 / M > 0 ? 65533 / M : 1;
+    const int64_t min_streams = mpc_cdiv(n_loc, per);
+    MPC_REQUIRE(ctx, min_streams <= max_streams, "rans_encode_auto: max_streams is below what the 16-bit stream length needs (%lld)",
+                (long long)min_streams);
+    Geometry g;
+    int rc = check_geometry(ctx, g, K, M, L, n_images, n_loc, max_streams, (int)mpc_cdiv(n_loc, max_streams));
+    if (rc) return rc;
+    MPC_REQUIRE(ctx, ((uintptr_t)out % 4) == 0 && out_stride % 4 == 0 && ((uintptr_t)workspace % 256) == 0,
+                "rans_encode_auto: out must be 4-byte aligned with a stride multiple of 4; workspace 256-byte aligned");
+    Workspace w = carve_max(workspace, n_images, n_loc, M, max_streams);
+    if (w.bytes > workspace_bytes) MPC_FAIL(ctx, MPC_ENOMEM, "rans_encode_auto: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+    MPC_REQUIRE(ctx, out_stride >= 16 + 2 * (size_t)max_streams, "rans_encode_auto: out_stride smaller than the largest header");
+    choose_geometry_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(minbits, (int64_t)n_images * n_loc, n_images, n_loc, M, budget,
+                                                                   max_streams, geometry_dev);
+    MPC_CHECK_LAUNCH(ctx, "rans choose_geometry");
+    return rans_encode_launch(ctx, g, table, idx, sym, w, out, out_stride, nbytes_dev, status_dev, geometry_dev);
+}
+
+}  // extern "C"
 
 // Shared body of the two decode entry points.  `aligned_rows`: device buffer of K*M*DMA_PITCH uint16 for the
 // 16-byte aligned copy of the table (L == 257 only; unused otherwise).
@@ -658,6 +767,8 @@ static int rans_decode_check(mpc_ctx *ctx, Geometry &g, const int16_t *table, in
                 "rans_decode: in_stride smaller than the container header (or >= 4 GiB)");
     return MPC_OK;
 }
+
+extern "C" {
 
 int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const uint8_t *in,
                     size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int n_streams,

@@ -20,6 +20,13 @@ from .Balle2018PT_compressor import Analysis_net, Synthesis_net
 from .bitEstimator import MultiHeadBitEstimator
 
 TRY_PNG_SIDESTRING = True      # pt_helpers.get_num_bits(try_png=...) for bpp_sidestring
+HOST_TRACE = None              # a list: encode_batch / decode_batch append (label, time.perf_counter()) at their host-side milestones
+
+
+def _mark(label):
+    if HOST_TRACE is not None:
+        import time
+        HOST_TRACE.append((label, time.perf_counter()))
 
 
 class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImageCompressor):
@@ -137,11 +144,16 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         x = input_image.contiguous()
         B, _, H, W = x.shape
         npix = B * H * W
-        _, yhat = self._analysis(x)
+        while True:
+            yhat, sym4, nclamp = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1,
+                                                              keep_rounded=True)
+            if int(nclamp.item()) == 0:
+                break
+            self._widen_tables()
         _, h, w, M = yhat.shape
         recon = self.Decoder.forward_nhwc(yhat)
         xhat, visual_loss = self._visual_loss(recon, x)
-        sym = self._symbols(yhat)
+        sym = sym4.view(-1, M)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
         dist_select = idx.view(B, h, w)
         self.last_dist_select = dist_select          # the prior index map of the last forward (int32 [B,h,w], on the GPU)
@@ -197,20 +209,63 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
             self._stage_buf = buf
         return buf
 
+    def _meta_host(self, n):
+        """Page-locked int32 host buffer for the one small readback of a call."""
+        buf = getattr(self, "_meta_buf", None)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty(max(n, 256), dtype=torch.int32, pin_memory=True)
+            self._meta_buf = buf
+        return buf[:n]
+
     def encode_batch(self, input_image, entropy_coding=True):
-        """Batched encode: -> (list of byte strings | int16 symbols [B, h*w*M], idx int32 [B, h*w], h, w)."""
+        """Batched encode: -> (list of byte strings | int16 symbols [B, h*w*M], idx int32 [B, h*w], h, w).
+
+        The whole chain -- g_a with quantisation and symbolisation in the last layer's epilogue, prior competition, the
+        coder with its stream geometry chosen on the device from the competition's bit estimate -- is enqueued without
+        the host reading anything back.  One small readback follows (sizes, coder status, clamped-symbol count), then
+        the copy of the used part of the bitstream slots."""
         self._ensure_tables()
         x = input_image.contiguous()
-        B = x.shape[0]
-        _, yhat = self._analysis(x)
-        _, h, w, M = yhat.shape
-        sym = self._symbols(yhat)
+        B, M = x.shape[0], self.out_channel_M
+        dev = x.device
+        _mark("enc:start")
+        # one device buffer for everything the host reads back: nbytes int64[B] | status int32[B] | geometry int32[2] | clamped
+        meta = torch.empty(3 * B + 4, dtype=torch.int32, device=dev)
+        nbytes_d, status_d = meta[:2 * B].view(torch.int64), meta[2 * B:3 * B]
+        geom_d, nclamp_d = meta[3 * B:3 * B + 2], meta[3 * B + 2:3 * B + 3]
+        _, sym4, _ = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1, nclamp_d)
+        _, h, w, _ = sym4.shape
+        sym = sym4.view(-1, M)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_ln)
         if not entropy_coding:
+            if int(nclamp_d.item()):
+                self._widen_tables()
+                return self.encode_batch(input_image, entropy_coding)
             return sym.view(B, -1), idx.view(B, -1), h, w
-        est = float(ops.sum_f32(minbits).item()) / 8 / B
-        streams, _ = self._encode_symbols(sym, idx, B, est)
-        return streams, idx.view(B, -1), h, w
+        out, _, _, _ = ops.rans_encode_auto(self.entropy_table, idx, sym.reshape(-1), minbits, B, nbytes_d, status_d, geom_d)
+        host = self._meta_host(meta.numel())
+        host.copy_(meta, non_blocking=True)
+        _mark("enc:enqueued")
+        torch.cuda.current_stream(dev).synchronize()                   # the one blocking readback before the bitstream copy
+        _mark("enc:meta")
+        hm = host.numpy()
+        if int(hm[3 * B + 2]):
+            self._widen_tables()                                       # like the reference (manynets_compressor.py:212-227)
+            return self.encode_batch(input_image, entropy_coding)
+        nb = hm[:2 * B].view(np.int64).tolist()
+        st = hm[2 * B:3 * B].tolist()
+        if min(st) < 0:
+            raise _lib.MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
+        self.last_stream_geometry = (int(hm[3 * B]), int(hm[3 * B + 1]))
+        used = (max(nb) + 3) // 4 * 4
+        stage = self._staging(B * used)[:B * used]
+        ops.download_rows(out, used, stage)
+        torch.cuda.current_stream(dev).synchronize()
+        _mark("enc:bytes_on_host")
+        hb = stage.numpy().reshape(B, used)
+        res = [hb[i, :nb[i]].tobytes() for i in range(B)]
+        _mark("enc:strings")
+        return res, idx.view(B, -1), h, w
 
     def encode(self, input_image, entropy_coding=True, out_fpath=None):
         """One image -> [bitstream, indices int64 [h*w,1], h, w] (manynets_compressor.py:197-290).  With
@@ -242,26 +297,43 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         return self.decode([bitstream, indices, h, w])
 
     def decode_batch(self, streams: List[bytes], idx, h: int, w: int):
-        """List of MRS1 byte strings + idx [B, h*w] -> reconstruction NCHW (unclamped)."""
+        """List of MRS1 byte strings + idx [B, h*w] -> reconstruction NCHW (unclamped).
+
+        One host-to-device copy (sizes and strings together), then the coder and g_s are enqueued back to back; the
+        decoder's status is read back while g_s runs and checked before the result is returned."""
         self._ensure_tables()
         B, M = len(streams), self.out_channel_M
         dev = self.entropy_table.device
         if idx.numel() != B * h * w:
             raise ValueError(f"decode_batch: {idx.numel()} prior indices for {B} images of {h}x{w} locations")
+        _mark("dec:start")
         n_streams, lps = ops.parse_mrs1_headers(streams, h * w, M)
         stride = (max(len(s) for s in streams) + 3) // 4 * 4
-        stage = self._staging(B * stride)[:B * stride].view(B, stride)   # bytes past a stream's end are never read
+        total = 8 * B + B * stride
+        stage = self._staging(total)[:total]
         host = stage.numpy()
+        host[:8 * B].view(np.int64)[:] = [len(s) for s in streams]
+        rows = host[8 * B:].reshape(B, stride)                          # bytes past a stream's end are never read
         for i, s in enumerate(streams):
-            host[i, :len(s)] = np.frombuffer(s, np.uint8)
-        data = stage.to(dev, non_blocking=True)
-        nbytes = torch.tensor([len(s) for s in streams], dtype=torch.int64).to(dev, non_blocking=True)
+            rows[i, :len(s)] = np.frombuffer(s, np.uint8)
+        _mark("dec:staged")
+        buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        buf.copy_(stage, non_blocking=True)
+        nbytes, data = buf[:8 * B].view(torch.int64), buf[8 * B:].view(B, stride)
         idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
         sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, lps)
-        if int(status.min().item()) < 0:
-            raise _lib.MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
-        yhat = ops.symbols_to_latent(sym.view(B, h, w, M), self.min_feat, self.q_intv)
-        return self.Decoder.forward_nhwc(yhat)
+        st_host = self._meta_host(B)
+        st_host.copy_(status, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        recon = self.Decoder.forward_nhwc(self.Decoder.latent_from_symbols(sym.view(B, h, w, M), self.min_feat, self.q_intv))
+        _mark("dec:enqueued")
+        done.synchronize()                                              # the coder has finished; g_s is still running
+        _mark("dec:status")
+        st = st_host.tolist()
+        if min(st) < 0:
+            raise _lib.MpcError(f"corrupt MRS1 stream: decoder status {st}")
+        return recon
 
     def decode(self, bitstream, in_fpath=None):
         """Tensor latent (NCHW) -> g_s(latent); [bytes, indices, h, w] or files written by encode() ->

@@ -5,6 +5,7 @@ stream of the tensor's device.  There is no fallback: a CPU tensor or a missing 
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -266,7 +267,8 @@ def choose_streams(n_loc: int, M: int, est_bytes: float, budget: float = 0.004, 
     """(n_streams, locs_per_stream): as many streams as fit in `budget` of the estimated payload, at least
     what the 16-bit stream-length field requires, at most one location per stream."""
     min_streams = -(-n_loc // max(1, MRS1_MAX_SYMBOLS_PER_STREAM // M))
-    want = int(max(0.0, est_bytes * budget - MRS1_FIXED_HEADER) // MRS1_STREAM_OVERHEAD)
+    w = est_bytes * budget - MRS1_FIXED_HEADER
+    want = int(math.floor(w / MRS1_STREAM_OVERHEAD)) if w > 0.0 else 0       # (NaN: no extra streams) same rule on the device
     n = max(min_streams, min(want, max_streams, n_loc), 1)
     lps = -(-n_loc // n)
     n = -(-n_loc // lps)                 # drop streams that would be empty
@@ -296,6 +298,57 @@ def rans_encode(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_ima
         ctx.call("mpc_rans_encode", ptr(table), K, M, L, ptr(idx), ptr(sym), n_images, n_loc, n_streams, locs_per_stream,
                  ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status))
     return out, nbytes, status
+
+
+MRS1_STREAM_BUDGET = 0.004       # share of the estimated payload that the per-stream overhead may take
+MRS1_MAX_STREAMS = 4096
+
+
+def rans_encode_auto(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, minbits: torch.Tensor, n_images: int,
+                     nbytes: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None,
+                     geometry: Optional[torch.Tensor] = None, budget: float = MRS1_STREAM_BUDGET,
+                     max_streams: int = MRS1_MAX_STREAMS):
+    """rans_encode with the stream geometry chosen on the device from `minbits` (the competition's minima), by the rule
+    of choose_streams: nothing is read back before the coder is launched.  nbytes (int64 [n_images]), status (int32
+    [n_images]) and geometry (int32 [2] = n_streams, locs_per_stream) may be caller-provided device tensors (slots of one
+    readback buffer).  -> (out uint8 [n_images, out_stride], nbytes, status, geometry)."""
+    _dev(table, torch.int16, "table"); _dev(idx, torch.int32, "idx"); _dev(sym, torch.int16, "sym")
+    _dev(minbits, torch.float32, "minbits")
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    if sym.numel() != idx.numel() * M or minbits.numel() != idx.numel():
+        raise MpcError("rans_encode_auto: sym must hold M symbols and minbits one value per location")
+    dev = table.device
+    max_streams = max(1, min(max_streams, n_loc))
+    out_stride = (MRS1_FIXED_HEADER + max_streams * MRS1_STREAM_OVERHEAD + 2 * n_loc * M + 3) // 4 * 4
+    ctx = context_for(dev)
+    ws_bytes = ctx.lib.mpc_rans_auto_workspace_bytes(n_images, n_loc, M, max_streams)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((n_images, out_stride), dtype=torch.uint8, device=dev)
+    nbytes = torch.empty(n_images, dtype=torch.int64, device=dev) if nbytes is None else _dev(nbytes, torch.int64, "nbytes")
+    status = torch.empty(n_images, dtype=torch.int32, device=dev) if status is None else _dev(status, torch.int32, "status")
+    geometry = torch.empty(2, dtype=torch.int32, device=dev) if geometry is None else _dev(geometry, torch.int32, "geometry")
+    with _timed("rans_encode", symbols=n_images * n_loc * M):
+        ctx.call("mpc_rans_encode_auto", ptr(table), K, M, L, ptr(idx), ptr(sym), ptr(minbits), n_images, n_loc,
+                 ctypes.c_double(budget), max_streams, ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status), ptr(geometry))
+    return out, nbytes, status, geometry
+
+
+def download_rows(src: torch.Tensor, width: int, dst_host: torch.Tensor) -> None:
+    """Asynchronous copy of the first `width` bytes of every row of the 2-D uint8 device tensor `src` into the
+    (page-locked) host tensor dst_host [rows, width], on the current stream."""
+    _dev(src, torch.uint8, "src")
+    rows = src.shape[0]
+    if dst_host.is_cuda or dst_host.dtype != torch.uint8 or dst_host.numel() < rows * width or not dst_host.is_contiguous():
+        raise MpcError("download_rows: dst_host must be a contiguous uint8 host tensor of rows*width bytes")
+    context_for(src.device).call("mpc_download_rows", ptr(src), src.stride(0), width, rows, ptr(dst_host), width)
+
+
+def symbols_to_latent_f16(sym: torch.Tensor, min_feat: int, q_intv: int) -> torch.Tensor:
+    _dev(sym, torch.int16, "sym")
+    out = torch.empty(sym.shape, dtype=torch.float16, device=sym.device)
+    context_for(sym.device).call("mpc_symbols_to_latent_f16", ptr(sym), sym.numel(), int(min_feat), int(q_intv), ptr(out))
+    return out
 
 
 def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int,
@@ -539,6 +592,37 @@ class ConvLayer:
         with _timed(self.kernel_name, flops=self.flops(B, H, W)):
             context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))
         return (out, outr) if round_out else out
+
+    def forward_symbols(self, x: torch.Tensor, min_feat: int, n_sym_values: int, n_clamped: Optional[torch.Tensor] = None,
+                        keep_rounded: bool = False):
+        """The last analysis layer with quantisation and symbolisation fused: -> (round(y) fp32 NHWC | None, int16 symbols
+        NHWC, int32[1] count of clamped values).  `n_clamped` may be a caller-provided int32 device tensor (a slot of a
+        larger readback buffer)."""
+        if self.f16 or self.small_cout or self.act != _lib.MPC_ACT_NONE:
+            raise MpcError("forward_symbols needs a layer without activation on the f32 or f16x3 path")
+        if self.x3 and self.cin > 4:
+            _dev(x, torch.float16, "x")
+            if x.dim() != 5 or x.shape[3] * 8 != self.cin or x.shape[4] != 16:
+                raise MpcError(f"f16x3 layer expects a split tensor [B,H,W,{self.cin // 8},16], got {tuple(x.shape)}")
+        else:
+            _dev(x, torch.float32, "x")
+            if x.dim() != 4 or x.shape[3] != (4 if self.cin <= 4 else self.cin):
+                raise MpcError(f"input {tuple(x.shape)} does not match the layer's {self.cin} input channels")
+        B, H, W = x.shape[:3]
+        Ho, Wo = self.out_hw(H, W)
+        sym = torch.empty((B, Ho, Wo, self.cout), dtype=torch.int16, device=x.device)
+        outr = torch.empty((B, Ho, Wo, self.cout), dtype=torch.float32, device=x.device) if keep_rounded else None
+        if n_clamped is None:
+            n_clamped = torch.empty(1, dtype=torch.int32, device=x.device)
+        _dev(n_clamped, torch.int32, "n_clamped")
+        if self.x3:
+            base = B * Ho * Wo
+            wide = -(-base // 256) * self._launches >= 512
+            self.kernel_name = self._name_fmt % (8 if wide else 4)
+        with _timed(self.kernel_name, flops=self.flops(B, H, W)):
+            context_for(x.device).call("mpc_conv_forward_symbols", self.handle, ptr(x), B, H, W, int(min_feat), int(n_sym_values),
+                                       ptr(outr), ptr(sym), ptr(n_clamped))
+        return outr, sym, n_clamped
 
     def flops(self, B: int, H: int, W: int) -> float:
         """Algorithmic FLOPs of one forward: 2 per multiply-accumulate of the convolution (each real tap

@@ -2,6 +2,7 @@
 src/compression/models/testolina_compressor.py)."""
 import math
 
+import torch
 from torch import nn
 
 from . import _lib, abstract_model, manynets_compressor
@@ -39,7 +40,7 @@ class Testolina_Synthesis_net(_FusedNet):
     def forward_nhwc(self, y):
         from . import ops
         ls = self.layers()
-        t = ops.f32_to_f16(y) if self.precision == "fp16" else y
+        t = ops.f32_to_f16(y) if (self.precision == "fp16" and y.dtype != torch.float16) else y
         for layer in ls[:-1]:
             t = layer(t)
         return ls[-1](t, nchw_out=True)
@@ -47,6 +48,10 @@ class Testolina_Synthesis_net(_FusedNet):
     def forward(self, x):
         from . import ops
         return self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous()))
+
+    def latent_from_symbols(self, sym, min_feat, q_intv):
+        from . import ops
+        return ops.symbols_to_latent_f16(sym, min_feat, q_intv) if self.precision == "fp16" else ops.symbols_to_latent(sym, min_feat, q_intv)
 
 
 class TestolinaHP_ImageCompressor(abstract_model.AbstractHyperpriorImageCompressor):

@@ -83,6 +83,16 @@ int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t
 int mpc_clamp_sse_batched(mpc_ctx *ctx, const float *recon, const float *target, int n_images,
                           int64_t n_per_image, int score_clamped, float *xhat, double *sse_dev);
 
+/* latent[i] as fp16 (the input type of an MPC_F16 layer stack), same arithmetic as mpc_symbols_to_latent. */
+int mpc_symbols_to_latent_f16(mpc_ctx *ctx, const int16_t *sym, int64_t n, int min_feat, int q_intv,
+                              void *latent_f16);
+/* Asynchronous copy of `rows` rows of `width` bytes from device memory (row pitch src_pitch) to HOST memory (row pitch
+ * dst_pitch; page-locked memory keeps it asynchronous) on the context's stream: brings the used part of every
+ * image's worst-case-sized bitstream slot to the host in one call (the reference copies the whole CDF tensor to
+ * the host instead, manynets_compressor.py:274). */
+int mpc_download_rows(mpc_ctx *ctx, const void *src_dev, size_t src_pitch, size_t width, size_t rows,
+                      void *dst_host, size_t dst_pitch);
+
 /* ---- image-quality statistics of the reference's test harness (src/compression/tests.py:393-418) ------------- */
 /* Sums over the valid region ((H-win_size+1) x (W-win_size+1)) of the SSIM map and of the contrast-structure map
  * of every plane of x and y ([planes][H][W] fp32, planes = batch*channels), with the separable window `window`
@@ -156,6 +166,18 @@ int mpc_rans_encode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
                     const int16_t *sym, int n_images, int64_t n_loc, int n_streams, int locs_per_stream,
                     void *workspace, size_t workspace_bytes, uint8_t *out, size_t out_stride,
                     uint64_t *nbytes_dev, int32_t *status_dev);
+/* mpc_rans_encode with the stream geometry chosen ON THE DEVICE, so that the host does not have to read the bit
+ * estimate back before it can launch the coder: est = sum(minbits) / 8 / n_images bytes per image (minbits: the
+ * n_images*n_loc minima of mpc_prior_argmin), n_streams = the largest count whose 6 bytes per stream stay within
+ * `budget` (e.g. 0.004) of est, at least what the 16-bit stream length needs, at most max_streams and n_loc;
+ * locs_per_stream = ceil(n_loc / n_streams), empty streams dropped.  geometry_dev (device int32[2]) receives
+ * {n_streams, locs_per_stream}; the containers' headers carry them too.  out_stride must hold the largest header
+ * (16 + 2*max_streams) plus the payload; the workspace is sized by mpc_rans_auto_workspace_bytes. */
+size_t mpc_rans_auto_workspace_bytes(int n_images, int64_t n_loc, int M, int max_streams);
+int mpc_rans_encode_auto(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                         const int16_t *sym, const float *minbits, int n_images, int64_t n_loc, double budget,
+                         int max_streams, void *workspace, size_t workspace_bytes, uint8_t *out,
+                         size_t out_stride, uint64_t *nbytes_dev, int32_t *status_dev, int32_t *geometry_dev);
 /* Decodes n_images containers (in + i*in_stride, nbytes_dev[i] bytes; nbytes_dev is a device array)
  * into sym_out + i*n_loc*M.  n_streams / locs_per_stream are the values the containers were written
  * with (fields 1 and 3 of the header; every image of the batch must share them).  status_dev[i]
@@ -234,6 +256,13 @@ int mpc_conv_out_hw(const mpc_conv *conv, int H, int W, int *Ho, int *Wo);
  * NULL) receives the unrounded values and `out_round` the rounded ones. */
 int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W,
                      int flags, void *out, float *out_round);
+/* The last layer of g_a with quantisation and symbolisation fused into its epilogue: a layer without activation on
+ * the f32 or MPC_F16X3 path writes sym[pixel][c] = clamp(rint(conv + bias) - min_feat, 0, n_sym_values - 1) as int16
+ * (NHWC = the reference's symbol order) and, if out_round is not NULL, rint(conv + bias) as fp32 NHWC.
+ * *n_clamped_dev (device int32, may be NULL; zeroed by this call) counts clamped values.
+ * torch.round + ((y_hat - min_feat)/q_intv).round().short(), manynets_compressor.py:204, :264-269, with q_intv = 1. */
+int mpc_conv_forward_symbols(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W, int min_feat,
+                             int n_sym_values, float *out_round, int16_t *sym, int32_t *n_clamped_dev);
 /* fp32 <-> fp16 conversion of n contiguous elements (saturating to +-65504), for the boundaries of an
  * MPC_F16 layer stack. */
 int mpc_f32_to_f16(mpc_ctx *ctx, const float *in, int64_t n, void *out_f16);
