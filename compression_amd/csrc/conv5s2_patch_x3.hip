@@ -1,0 +1,259 @@
+// Split-precision (f16x3) 5x5 stride-2 convolution with the input staged through LDS as a 2-D patch: the kernel of
+// the two big layers of the analysis transform (conv2, conv3: 192 -> 192 with fused GDN) and of conv4.
+//
+// Why: a 5x5 stride-2 layer reads every input pixel 25/4 times, once per tap.  With activations fetched global ->
+// registers per tap (conv_igemm_x3.hip) those re-reads miss the 4 MB L2 of an XCD (5x the compulsory bytes went over
+// the fabric) and their latency sits on the K loop.  Here a workgroup owns a 16 x TR tile of output pixels and keeps
+// the (2 TR + 3) x 35 input pixels it needs, for 16 input channels at a time, in LDS: the patch is fetched once per
+// 16-channel block (1.2x the compulsory bytes, the halo) and all 25 taps read it from LDS.
+//
+// K walk: for each 16-channel block (one k-step of v_mfma_f32_32x32x16_f16), the 25 taps.  Per tap a wave issues
+// 3 MFMAs (hi*lo, lo*hi, hi*hi) for each of its NF output tiles; weights come through a double-buffered LDS chunk
+// (1 tap x 16 channels, the packed image of conv_igemm_x3.hip read in halves), one barrier per tap.  The patch of the
+// NEXT block is fetched into registers during the first taps of the current block (one 16-byte load per tap and
+// thread) and written to LDS between the blocks.
+//
+// Patch image in LDS (16-byte slots): [row][column parity 2][piece 4][x2 18], piece = (k half h, hi|lo).  A wave's 32
+// pixels are two tile rows of 16; for one tap the 16 lanes of a row read 16 consecutive slots (input columns two
+// apart share a parity), and two patch rows are 2 x 2304 bytes = a multiple of the 256-byte bank row apart, so the
+// 16-lane groups of ds_read_b128 are conflict free.
+//
+// Same operand formats, scales, GDN continuation and epilogues as conv_igemm_x3.hip; only the summation order of
+// the K axis differs (channel block major), so results agree with it to fp32 rounding, not bit for bit.
+#include "conv_x3_epilogue.h"
+
+namespace {
+
+constexpr int TILE_W = 16;
+constexpr int PATCH_COLS = 2 * TILE_W + 3;          // 35
+constexpr int X2 = 18;                              // columns per parity (35 = 18 even + 17 odd, one slot of padding)
+constexpr int ROW_F4 = 2 * 4 * X2;                  // 144 slots = 2304 bytes per patch row
+
+// 16 bytes as a native vector: arrays of HIP's float4 struct that are written under masks stay in scratch memory
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
+
+template <int NF, int EPI, int TR>
+__global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Params p) {
+    constexpr int NW = TR / 2, NT = 64 * NW, COUT = NF * 32;
+    constexpr int PR = 2 * TR + 3;                       // patch rows
+    constexpr int PATCH_F4 = PR * ROW_F4;
+    constexpr int NS = (PATCH_F4 + NT - 1) / NT;         // patch slots staged per thread (one load per tap)
+    constexpr int WCH_F4 = COUT * 4;                     // slots of a weight chunk (1 tap x 16 channels): [h][hi|lo][cout]
+    constexpr int WST = (WCH_F4 + NT - 1) / NT;
+    static_assert(NS <= 25, "one staged patch slot per tap");
+    extern __shared__ f4 lds[];
+    f4 *patch = lds;
+    f4 *wbuf = lds + PATCH_F4;                       // 2 x WCH_F4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int cg = blockIdx.z * COUT;
+
+    const int tiles_x = (p.Wo + TILE_W - 1) / TILE_W, tiles_y = (p.Ho + TR - 1) / TR;
+    const int64_t blk = xcd_block();
+    if (blk >= (int64_t)p.B * tiles_y * tiles_x) return;     // padding block of the rounded-up grid
+    const int b = (int)(blk / (tiles_y * tiles_x));
+    const int trem = (int)(blk - (int64_t)b * tiles_y * tiles_x);
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy = ty * TR + 2 * wave + (j >> 4), ox = tx * TILE_W + (j & 15);
+    const bool pvalid = oy < p.Ho && ox < p.Wo;
+    const int iy0 = 2 * ty * TR - 2, ix0 = 2 * tx * TILE_W - 2;
+
+    // ---- patch staging: slot s = tid + i*NT of the LDS image <- 16 bytes of the S16 input -------------------
+    const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs * 2;
+    int soff[NS];                                         // element (half) offset inside the image, -1 = zero
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int s = tid + i * NT;
+        const int r = s / ROW_F4, rem = s - r * ROW_F4;
+        const int par = rem / (4 * X2), rem2 = rem - par * (4 * X2);
+        const int q = rem2 / X2, x2 = rem2 - q * X2;
+        const int px = 2 * x2 + par, iy = iy0 + r, ix = ix0 + px;
+        const bool ok = s < PATCH_F4 && px < PATCH_COLS && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        soff[i] = ok ? (iy * p.Wi + ix) * p.Cs * 2 + q * 8 : -1;
+    }
+    f4 stage[NS];
+    // every load is unconditional (a slot outside the image loads the image's first bytes and is zeroed when it is
+    // written to LDS): no branch around a load, no early wait
+    auto load_slot = [&](int i, int cb) { stage[i] = *(const f4 *)(in_b + (soff[i] >= 0 ? soff[i] : 0) + cb * 32); };
+    auto write_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (tid + i * NT < PATCH_F4) patch[tid + i * NT] = soff[i] >= 0 ? stage[i] : f4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- weights: chunk (tap, cb) of the packed image, register-staged into the LDS double buffer -----------
+    const int ncb = p.Cs / 16;                            // 16-channel blocks
+    const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group);
+    const bool gdn_mix16 = (EPI == EPI_GDN) && p.y2_scale > 0.0f;
+    const f4 *gsrc = (const f4 *)p.gamma_x3;
+    f4 wreg[WST];
+    auto load_w = [&](const f4 *chunk_src) {                 // unconditional: surplus threads re-read the last slot
+#pragma unroll
+        for (int r = 0; r < WST; ++r) {
+            const int sl = tid + r * NT;
+            wreg[r] = chunk_src[(WCH_F4 % NT == 0 || sl < WCH_F4) ? sl : WCH_F4 - 1];
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < WST; ++r)
+            if (WCH_F4 % NT == 0 || tid + r * NT < WCH_F4) wbuf[buf * WCH_F4 + tid + r * NT] = wreg[r];
+    };
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    // prologue: patch of block 0, weights of (tap 0, block 0)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) load_slot(i, 0);
+    load_w(wsrc);
+    write_patch();
+    store_w(0);
+    __syncthreads();
+
+    // this lane's pixel in the patch: row 2*(row in tile), piece 2h (hi) / 2h+1 (lo), column slot (j & 15)
+    const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * ROW_F4 + (2 * h) * X2 + (j & 15);
+    int c = 0;                                            // chunks done: chunk c sits in wbuf[c & 1]
+    // One tap of the current 16-channel block.  Expanded 25 times with a literal tap number: the staging registers
+    // are then addressed by constants (an array indexed by a loop counter ended up in scratch memory).
+#define MPC_PATCH_TAP(TAP)                                                                                             \
+    {                                                                                                                  \
+        constexpr int tap = (TAP), dyp = tap / 5, dxp = tap % 5;                                                      \
+        /* next chunk: (tap + 1, cb), or (0, cb + 1), or after the last one the first half chunk of gamma */          \
+        const f4 *nsrc = (tap < 24) ? wsrc + ((int64_t)(tap + 1) * ncb + cb) * WCH_F4                              \
+                             : more      ? wsrc + (int64_t)(cb + 1) * WCH_F4                                           \
+                             : gdn_mix16 ? gsrc                                                                        \
+                                         : wsrc;                                                                       \
+        load_w(nsrc);                                                                                                  \
+        if constexpr (tap < NS) load_slot(tap, more ? cb + 1 : cb); /* (the last block re-reads its own: unused) */   \
+        const f4 *bp = bbase + dyp * ROW_F4 + (dxp & 1) * (4 * X2) + (dxp >> 1);                                   \
+        const half8 bh = as_half8(bp[0]), bl = as_half8(bp[X2]);                                                       \
+        const f4 *wl = wbuf + (c & 1) * WCH_F4 + (h * 2) * COUT + j;                                               \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                               \
+            const half8 ah = as_half8(wl[f * 32]);                                                                     \
+            const half8 al = as_half8(wl[COUT + f * 32]);                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[f], 0, 0, 0);                                  \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
+        }                                                                                                              \
+        store_w((c + 1) & 1);                                                                                          \
+        __syncthreads();                                                                                               \
+        ++c;                                                                                                           \
+    }
+    for (int cb = 0; cb < ncb; ++cb) {
+        const bool more = cb + 1 < ncb;
+        MPC_PATCH_TAP(0) MPC_PATCH_TAP(1) MPC_PATCH_TAP(2) MPC_PATCH_TAP(3) MPC_PATCH_TAP(4)
+        MPC_PATCH_TAP(5) MPC_PATCH_TAP(6) MPC_PATCH_TAP(7) MPC_PATCH_TAP(8) MPC_PATCH_TAP(9)
+        MPC_PATCH_TAP(10) MPC_PATCH_TAP(11) MPC_PATCH_TAP(12) MPC_PATCH_TAP(13) MPC_PATCH_TAP(14)
+        MPC_PATCH_TAP(15) MPC_PATCH_TAP(16) MPC_PATCH_TAP(17) MPC_PATCH_TAP(18) MPC_PATCH_TAP(19)
+        MPC_PATCH_TAP(20) MPC_PATCH_TAP(21) MPC_PATCH_TAP(22) MPC_PATCH_TAP(23) MPC_PATCH_TAP(24)
+        if (more) {                                       // every wave has read the old patch (barrier above)
+            write_patch();
+            __syncthreads();
+        }
+    }
+#undef MPC_PATCH_TAP
+
+    // ---- epilogue -------------------------------------------------------------------------------------------
+    x3_unscale_bias<NF>(p, acc, cg, h);
+    const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+    if constexpr (EPI == EPI_GDN) {
+        // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as 2 NF more k-steps: half chunk (kc, s) holds gamma[:, 32kc+16s ..+15]
+        // in the weight-chunk layout; the B operand is built from the lane's own accumulators, whose registers
+        // 8s..8s+7 of tile kc are the 8 k-values of that k-step (c = 32kc + 16s + 8(jj>>2) + 4h + (jj&3)).
+        f32x16 nrm[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+#pragma unroll
+        for (int kc = 0; kc < NF; ++kc) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s, ++c) {
+                const int hc = 2 * kc + s;
+                load_w(gsrc + (int64_t)(hc + 1 < 2 * NF ? hc + 1 : hc) * WCH_F4);
+                const f4 *wl = wbuf + (c & 1) * WCH_F4 + (h * 2) * COUT + j;
+                half8 bh, bl;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    float y = acc[kc][8 * s + jj];
+                    float q = fminf(y * y * p.y2_scale, 65504.0f);
+                    _Float16 hh = (_Float16)q;
+                    bh[jj] = hh;
+                    bl[jj] = (_Float16)(q - (float)hh);
+                }
+#pragma unroll
+                for (int fo = 0; fo < NF; ++fo) {
+                    const half8 ah = as_half8(wl[fo * 32]);
+                    const half8 al = as_half8(wl[COUT + fo * 32]);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm[fo], 0, 0, 0);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
+                }
+                store_w((c + 1) & 1);
+                __syncthreads();
+            }
+        }
+        x3_gdn_store<NF>(p, acc, nrm, (float4 *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
+    } else {
+        if (!pvalid) return;
+        x3_plain_store<NF>(p, acc, cg, h, opix);
+    }
+}
+
+template <int NF, int EPI, int TR>
+int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
+    constexpr int NW = TR / 2;
+    size_t lds = ((size_t)(2 * TR + 3) * ROW_F4 + 2 * (size_t)NF * 32 * 4) * sizeof(float4);
+    if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    auto kern = conv5s2_patch_x3_kernel<NF, EPI, TR>;
+    static bool attr_set[MPC_MAX_DEVICES] = {};
+    bool &attr_done = attr_set[ctx->device];
+    if (!attr_done) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int64_t tiles = (int64_t)p.B * mpc_cdiv(p.Ho, TR) * mpc_cdiv(p.Wo, TILE_W);
+    const int64_t bx = xcd_grid(tiles);
+    MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many tiles");
+    kern<<<dim3((unsigned)bx, 1, (unsigned)groups), dim3(64 * NW), lds, ctx->stream>>>(p);
+    MPC_CHECK_LAUNCH(ctx, "conv5s2_patch_x3");
+    return MPC_OK;
+}
+
+}  // namespace
+
+// True when the layer / call can run on the patch kernel.
+bool mpc_conv_patch_x3_supported(const Params &p, const mpc_conv *c) {
+    const mpc_conv_desc &d = c->desc;
+    const bool gdn = d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN;
+    if (!c->x3 || c->cin4 || d.kind != MPC_CONV || d.ksize != 5 || d.stride != 2 || d.pad != 2) return false;
+    if (d.cin % 32 != 0 || (c->nf != 4 && c->nf != 6)) return false;
+    if (gdn && !(p.gamma_x3 && p.y2_scale > 0.0f)) return false;        // the exact f32 channel mix lives in the other kernel
+    if (!gdn && d.act != MPC_ACT_NONE && d.act != MPC_ACT_RELU) return false;
+    if ((int64_t)p.Hi * p.Wi * p.Cs * 2 >= (1ll << 31)) return false;    // 32-bit element offsets inside one image
+    return true;
+}
+
+// rows: 16 or 8 tile rows (8 or 4 waves per workgroup).
+int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c, int rows) {
+    const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
+    const int ng = c->groups;
+    if (rows == 16) {
+        if (gdn && c->nf == 6) return launch_tr<6, EPI_GDN, 16>(ctx, p, ng);
+        if (gdn && c->nf == 4) return launch_tr<4, EPI_GDN, 16>(ctx, p, ng);
+        if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 16>(ctx, p, ng);
+        if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 16>(ctx, p, ng);
+    } else {
+        if (gdn && c->nf == 6) return launch_tr<6, EPI_GDN, 8>(ctx, p, ng);
+        if (gdn && c->nf == 4) return launch_tr<4, EPI_GDN, 8>(ctx, p, ng);
+        if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 8>(ctx, p, ng);
+        if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 8>(ctx, p, ng);
+    }
+    MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16x3 patch kernel): unsupported layer shape (cout/32 = %d)", c->nf);
+}

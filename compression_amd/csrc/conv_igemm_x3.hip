@@ -17,28 +17,11 @@
 //            (1 tap x 32 input channels) as [kstep 2][h 2][hi|lo][cout][8] fp16.
 // GDN stays on the exact f32 MFMA (4 % of the MACs) on the unscaled fp32 accumulators.
 // Same orientation / work decomposition / LDS weight staging as conv_igemm.hip.
-#include "conv_common.h"
+#include <stdlib.h>
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#include "conv_x3_epilogue.h"
 
 namespace {
-
-__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
-
-__device__ __forceinline__ void split_store4(_Float16 *blk, int off, const float (&v)[4]) {
-    // v already scaled; hi at blk[off..off+3], lo at blk[8+off..]
-    half4 hi, lo;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float s = fminf(fmaxf(v[t], -65504.0f), 65504.0f);
-        _Float16 hh = (_Float16)s;
-        hi[t] = hh;
-        lo[t] = (_Float16)(s - (float)hh);
-    }
-    *(half4 *)(blk + off) = hi;
-    *(half4 *)(blk + 8 + off) = lo;
-}
 
 // RGB = first layer: the input is the fp32 NHWC image padded to 4 channels; the K axis is the im2col index
 // k = tap*4 + c (8 taps per chunk, 25 taps -> 4 chunks; the weights of c = 3 and of the padding taps are
@@ -193,17 +176,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
     }
 
     // ---- epilogue: undo the operand scales, add bias ---------------------------------------------
-    const float unscale = p.x3_unscale;
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 bb = *(const float4 *)(p.bias + cg + 32 * f + 8 * g + 4 * h);
-            acc[f][4 * g + 0] = acc[f][4 * g + 0] * unscale + bb.x;
-            acc[f][4 * g + 1] = acc[f][4 * g + 1] * unscale + bb.y;
-            acc[f][4 * g + 2] = acc[f][4 * g + 2] * unscale + bb.z;
-            acc[f][4 * g + 3] = acc[f][4 * g + 3] * unscale + bb.w;
-        }
+    x3_unscale_bias<NF>(p, acc, cg, h);
     const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
     const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
     const bool out_split = (p.flags & MPC_OUT_SPLIT) != 0;
@@ -247,44 +220,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
                 store_w((nch + kc + 1) & 1, wreg);
                 __syncthreads();
             }
-            // y * (beta + norm)^(-1/2) (or ^(+1/2)); v_rsq_f32 is good to 1 ulp
-            TransStore ts;
-            ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const int rbase = (f % 3) * 128;              // byte offset of this tile inside the round's row
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 be = *(const float4 *)(p.beta + 32 * f + 8 * g + 4 * h);
-                    const float bev[4] = {be.x, be.y, be.z, be.w};
-                    float o[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float a = nrm[f][4 * g + t] * p.gdn_unscale + bev[t];
-                        float rs = __builtin_amdgcn_rsqf(a);
-                        float y = acc[f][4 * g + t];
-                        o[t] = inverse ? y * (a * rs) : y * rs;
-                    }
-                    if (out_split) {
-                        // block g of the tile: [hi x8 | lo x8]; this lane half owns elements 4h..4h+3 of each
-                        half4 hi4, lo4;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
-                            _Float16 hh = (_Float16)sv;
-                            hi4[t] = hh;
-                            lo4[t] = (_Float16)(sv - (float)hh);
-                        }
-                        *(half4 *)ts.at(j, rbase + g * 32 + 8 * h) = hi4;
-                        *(half4 *)ts.at(j, rbase + g * 32 + 16 + 8 * h) = lo4;
-                    } else {
-                        *(float4 *)ts.at(j, rbase + (8 * g + 4 * h) * 4) = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                }
-                // 96 channels (384 bytes per pixel) per round
-                if (f % 3 == 2) ts.template flush<24>((char *)p.out, pixel_bytes, (f / 3) * TS_ROW_BYTES);
-                else if (f == NF - 1) ts.template flush<(NF % 3) * 8>((char *)p.out, pixel_bytes, (f / 3) * TS_ROW_BYTES);
-            }
+            x3_gdn_store<NF>(p, acc, nrm, lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
             return;
         }
         // exact f32 channel mix (layers created without an input bound), one output tile at a time
@@ -351,33 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_x3_kernel(const Params 
         }
     } else {
         if (!pvalid) return;
-        float *out_f = (float *)p.out;
-        int sym_clamped = 0;
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int c0 = cg + 32 * f + 8 * g + 4 * h;
-                float o[4], orr[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float v = acc[f][4 * g + t];
-                    if (p.act == MPC_ACT_RELU) v = fmaxf(v, 0.0f);
-                    o[t] = v;
-                    orr[t] = rintf(v);
-                }
-                if (out_split) {
-                    float os[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) os[t] = o[t] * X3_ACT_SCALE;
-                    split_store4((_Float16 *)p.out + (opix * p.cout + (c0 & ~7)) * 2, c0 & 7, os);
-                } else {
-                    if (out_f) *(float4 *)(out_f + opix * p.cout + c0) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (p.out_round) *(float4 *)(p.out_round + opix * p.cout + c0) = make_float4(orr[0], orr[1], orr[2], orr[3]);
-                    if (p.out_sym) store_symbols4(p, opix * p.cout + c0, orr, sym_clamped);
-                }
-            }
-        if (sym_clamped && p.n_clamped) atomicAdd(p.n_clamped, sym_clamped);
+        x3_plain_store<NF>(p, acc, cg, h, opix);
     }
 }
 
@@ -408,6 +318,16 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
 }  // namespace
 
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    if (mpc_conv_patch_x3_supported(p, c)) {
+        // MPC_X3_PATCH (development switch): 0 = keep this file's kernel, 8 / 16 = force the tile height
+        static const int forced = [] { const char *e = getenv("MPC_X3_PATCH"); return e ? atoi(e) : -1; }();
+        if (forced != 0) {
+            // 8 rows: two independent 4-wave workgroups per CU, whose barriers fall out of phase (measured faster
+            // than one 8-wave workgroup of 16 rows: 3.14 against 3.47 ms on 24 x 256x384x192 inputs)
+            const int rows = (forced == 8 || forced == 16) ? forced : 8;
+            return mpc_conv_launch_patch_x3(ctx, p, c, rows);
+        }
+    }
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
     const int np = c->nphase, ng = c->groups;
     if (c->cin4) {
