@@ -33,6 +33,9 @@ constexpr int ROW_F4 = 2 * 4 * X2;                  // 144 slots = 2304 bytes pe
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
 
+// s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
+#define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+
 template <int NF, int EPI, int TR>
 __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Params p) {
     constexpr int NW = TR / 2, NT = 64 * NW, COUT = NF * 32;
@@ -40,11 +43,12 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
     constexpr int PATCH_F4 = PR * ROW_F4;
     constexpr int NS = (PATCH_F4 + NT - 1) / NT;         // patch slots staged per thread (one load per tap)
     constexpr int WCH_F4 = COUT * 4;                     // slots of a weight chunk (1 tap x 16 channels): [h][hi|lo][cout]
-    constexpr int WST = (WCH_F4 + NT - 1) / NT;
-    static_assert(NS <= 25, "one staged patch slot per tap");
+    constexpr int WPW = WCH_F4 / 64 / NW;                // 1 KB pieces of a chunk that each wave brings
+    static_assert(NS <= 24, "one staged patch slot per tap");
+    static_assert(WPW * NW * 64 == WCH_F4, "a weight chunk must split evenly into 1 KB pieces per wave");
     extern __shared__ f4 lds[];
     f4 *patch = lds;
-    f4 *wbuf = lds + PATCH_F4;                       // 2 x WCH_F4
+    f4 *wring = lds + PATCH_F4;                          // 3 x WCH_F4
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -83,23 +87,20 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             if (tid + i * NT < PATCH_F4) patch[tid + i * NT] = soff[i] >= 0 ? stage[i] : f4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // ---- weights: chunk (tap, cb) of the packed image, register-staged into the LDS double buffer -----------
+    // ---- weights: chunk (tap, cb) of the packed image, brought by LDS-DMA into a ring of three chunks -----------
+    // Chunk c + 2 is issued during tap c and has to have landed by the end of tap c + 1: two taps of latency for the
+    // weights, and -- the vector-memory counter retires in issue order -- for the patch load issued beside them.
     const int ncb = p.Cs / 16;                            // 16-channel blocks
     const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group);
     const bool gdn_mix16 = (EPI == EPI_GDN) && p.y2_scale > 0.0f;
     const f4 *gsrc = (const f4 *)p.gamma_x3;
-    f4 wreg[WST];
-    auto load_w = [&](const f4 *chunk_src) {                 // unconditional: surplus threads re-read the last slot
+    auto dma_chunk = [&](const f4 *chunk_src, int slot) {
 #pragma unroll
-        for (int r = 0; r < WST; ++r) {
-            const int sl = tid + r * NT;
-            wreg[r] = chunk_src[(WCH_F4 % NT == 0 || sl < WCH_F4) ? sl : WCH_F4 - 1];
+        for (int q = 0; q < WPW; ++q) {
+            const int piece = wave * WPW + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < WST; ++r)
-            if (WCH_F4 % NT == 0 || tid + r * NT < WCH_F4) wbuf[buf * WCH_F4 + tid + r * NT] = wreg[r];
     };
 
     f32x16 acc[NF];
@@ -108,32 +109,34 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
 
-    // prologue: patch of block 0, weights of (tap 0, block 0)
+    // prologue: weights of (tap 0, block 0) and (tap 1, block 0), patch of block 0
+    dma_chunk(wsrc, 0);
+    dma_chunk(wsrc + (int64_t)ncb * WCH_F4, 1);
 #pragma unroll
     for (int i = 0; i < NS; ++i) load_slot(i, 0);
-    load_w(wsrc);
     write_patch();
-    store_w(0);
+    MPC_WAIT_VMCNT(0);
     __syncthreads();
 
     // this lane's pixel in the patch: row 2*(row in tile), piece 2h (hi) / 2h+1 (lo), column slot (j & 15)
     const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * ROW_F4 + (2 * h) * X2 + (j & 15);
-    int c = 0;                                            // chunks done: chunk c sits in wbuf[c & 1]
-    // One tap of the current 16-channel block.  Expanded 25 times with a literal tap number: the staging registers
-    // are then addressed by constants (an array indexed by a loop counter ended up in scratch memory).
+    int slot = 0;                                         // ring slot of the current chunk; the chunk after next goes to slot + 2
+    // One tap of the current 16-channel block, expanded 25 times with a literal tap number: the staging registers are
+    // addressed by constants and the number of vector-memory operations that may stay in flight at the end of the tap
+    // (this tap's DMA pieces, its patch load, the previous tap's patch load) is a constant as well.
 #define MPC_PATCH_TAP(TAP)                                                                                             \
     {                                                                                                                  \
         constexpr int tap = (TAP), dyp = tap / 5, dxp = tap % 5;                                                      \
-        /* next chunk: (tap + 1, cb), or (0, cb + 1), or after the last one the first half chunk of gamma */          \
-        const f4 *nsrc = (tap < 24) ? wsrc + ((int64_t)(tap + 1) * ncb + cb) * WCH_F4                              \
-                             : more      ? wsrc + (int64_t)(cb + 1) * WCH_F4                                           \
-                             : gdn_mix16 ? gsrc                                                                        \
-                                         : wsrc;                                                                       \
-        load_w(nsrc);                                                                                                  \
+        /* chunk after next: (tap + 2, cb), or in the next block, or the first half chunks of gamma */                \
+        const f4 *nsrc = (tap < 23) ? wsrc + ((int64_t)(tap + 2) * ncb + cb) * WCH_F4                                  \
+                         : more      ? wsrc + ((int64_t)(tap - 23) * ncb + cb + 1) * WCH_F4                            \
+                         : gdn_mix16 ? gsrc + (int64_t)(tap - 23) * WCH_F4                                             \
+                                     : wsrc;                                                                           \
+        dma_chunk(nsrc, slot >= 1 ? slot - 1 : 2);                                                                     \
         if constexpr (tap < NS) load_slot(tap, more ? cb + 1 : cb); /* (the last block re-reads its own: unused) */   \
-        const f4 *bp = bbase + dyp * ROW_F4 + (dxp & 1) * (4 * X2) + (dxp >> 1);                                   \
+        const f4 *bp = bbase + dyp * ROW_F4 + (dxp & 1) * (4 * X2) + (dxp >> 1);                                       \
         const half8 bh = as_half8(bp[0]), bl = as_half8(bp[X2]);                                                       \
-        const f4 *wl = wbuf + (c & 1) * WCH_F4 + (h * 2) * COUT + j;                                               \
+        const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;                                                     \
         _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                               \
             const half8 ah = as_half8(wl[f * 32]);                                                                     \
             const half8 al = as_half8(wl[COUT + f * 32]);                                                              \
@@ -141,9 +144,10 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        store_w((c + 1) & 1);                                                                                          \
-        __syncthreads();                                                                                               \
-        ++c;                                                                                                           \
+        MPC_WAIT_VMCNT(WPW + (tap < NS ? 1 : 0) + ((tap >= 1 && tap - 1 < NS) ? 1 : 0));                               \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        slot = slot == 2 ? 0 : slot + 1;                                                                               \
     }
     for (int cb = 0; cb < ncb; ++cb) {
         const bool more = cb + 1 < ncb;
@@ -153,8 +157,9 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
         MPC_PATCH_TAP(15) MPC_PATCH_TAP(16) MPC_PATCH_TAP(17) MPC_PATCH_TAP(18) MPC_PATCH_TAP(19)
         MPC_PATCH_TAP(20) MPC_PATCH_TAP(21) MPC_PATCH_TAP(22) MPC_PATCH_TAP(23) MPC_PATCH_TAP(24)
         if (more) {                                       // every wave has read the old patch (barrier above)
-            write_patch();
-            __syncthreads();
+            write_patch();                                // (the staged registers' wait also retires the DMA issued before them)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
     }
 #undef MPC_PATCH_TAP
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 #pragma unroll
         for (int kc = 0; kc < NF; ++kc) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s, ++c) {
+            for (int s = 0; s < 2; ++s) {
                 const int hc = 2 * kc + s;
-                load_w(gsrc + (int64_t)(hc + 1 < 2 * NF ? hc + 1 : hc) * WCH_F4);
-                const f4 *wl = wbuf + (c & 1) * WCH_F4 + (h * 2) * COUT + j;
+                dma_chunk(gsrc + (int64_t)(hc + 2 < 2 * NF ? hc + 2 : 0) * WCH_F4, slot >= 1 ? slot - 1 : 2);
+                const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;
                 half8 bh, bl;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -195,12 +200,17 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
                 }
-                store_w((c + 1) & 1);
-                __syncthreads();
+                MPC_WAIT_VMCNT(WPW);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                slot = slot == 2 ? 0 : slot + 1;
             }
         }
+        MPC_WAIT_VMCNT(0);                                // the surplus DMA pieces have landed before the LDS is reused
+        __syncthreads();
         x3_gdn_store<NF>(p, acc, nrm, (float4 *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
     } else {
+        MPC_WAIT_VMCNT(0);                                // no DMA is left in flight when the workgroup ends
         if (!pvalid) return;
         x3_plain_store<NF>(p, acc, cg, h, opix);
     }
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 template <int NF, int EPI, int TR>
 int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
     constexpr int NW = TR / 2;
-    size_t lds = ((size_t)(2 * TR + 3) * ROW_F4 + 2 * (size_t)NF * 32 * 4) * sizeof(float4);
+    size_t lds = ((size_t)(2 * TR + 3) * ROW_F4 + 3 * (size_t)NF * 32 * 4) * sizeof(float4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
     auto kern = conv5s2_patch_x3_kernel<NF, EPI, TR>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
@@ -240,20 +250,14 @@ bool mpc_conv_patch_x3_supported(const Params &p, const mpc_conv *c) {
     return true;
 }
 
-// rows: 16 or 8 tile rows (8 or 4 waves per workgroup).
-int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c, int rows) {
+// 16 x 8 output tiles, 4 waves per workgroup, two workgroups per CU (2 x 80 640 bytes of LDS): their barriers fall
+// out of phase, so one's MFMAs cover the other's waits (one 8-wave workgroup of 16 rows measured 10 % slower).
+int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
     const int ng = c->groups;
-    if (rows == 16) {
-        if (gdn && c->nf == 6) return launch_tr<6, EPI_GDN, 16>(ctx, p, ng);
-        if (gdn && c->nf == 4) return launch_tr<4, EPI_GDN, 16>(ctx, p, ng);
-        if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 16>(ctx, p, ng);
-        if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 16>(ctx, p, ng);
-    } else {
-        if (gdn && c->nf == 6) return launch_tr<6, EPI_GDN, 8>(ctx, p, ng);
-        if (gdn && c->nf == 4) return launch_tr<4, EPI_GDN, 8>(ctx, p, ng);
-        if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 8>(ctx, p, ng);
-        if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 8>(ctx, p, ng);
-    }
+    if (gdn && c->nf == 6) return launch_tr<6, EPI_GDN, 8>(ctx, p, ng);
+    if (gdn && c->nf == 4) return launch_tr<4, EPI_GDN, 8>(ctx, p, ng);
+    if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 8>(ctx, p, ng);
+    if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 8>(ctx, p, ng);
     MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16x3 patch kernel): unsupported layer shape (cout/32 = %d)", c->nf);
 }

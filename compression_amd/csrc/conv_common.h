@@ -173,6 +173,6 @@ hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *ima
 int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // split-fp16 path (conv_igemm_x3.hip)
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
-// split-fp16 5x5 stride-2 layers with the input patch staged in LDS (conv5s2_patch_x3.hip); rows = 16 or 8 tile rows
+// split-fp16 5x5 stride-2 layers with the input patch staged in LDS (conv5s2_patch_x3.hip)
 bool mpc_conv_patch_x3_supported(const Params &p, const mpc_conv *c);
-int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c, int rows);
+int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);

@@ -319,14 +319,9 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
 
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     if (mpc_conv_patch_x3_supported(p, c)) {
-        // MPC_X3_PATCH (development switch): 0 = keep this file's kernel, 8 / 16 = force the tile height
-        static const int forced = [] { const char *e = getenv("MPC_X3_PATCH"); return e ? atoi(e) : -1; }();
-        if (forced != 0) {
-            // 8 rows: two independent 4-wave workgroups per CU, whose barriers fall out of phase (measured faster
-            // than one 8-wave workgroup of 16 rows: 3.14 against 3.47 ms on 24 x 256x384x192 inputs)
-            const int rows = (forced == 8 || forced == 16) ? forced : 8;
-            return mpc_conv_launch_patch_x3(ctx, p, c, rows);
-        }
+        // MPC_X3_PATCH=0 (development switch) keeps this file's kernel
+        static const bool off = [] { const char *e = getenv("MPC_X3_PATCH"); return e && atoi(e) == 0; }();
+        if (!off) return mpc_conv_launch_patch_x3(ctx, p, c);
     }
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
     const int np = c->nphase, ng = c->groups;
