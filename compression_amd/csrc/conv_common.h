@@ -1,5 +1,7 @@
 // Definitions shared by the f32 and f16 implicit-GEMM convolution kernels.
 #pragma once
+#include <stdlib.h>
+
 #include "mpc_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +65,8 @@ struct Params {
     int sym_max;
     int *n_clamped;       // number of symbols that had to be clamped (may be null)
     Phase ph[MAX_PHASES];
+    int2 tapv[MAX_TAPS];  // the tap table by value: indexed with a uniform index it is read by scalar loads, which the
+                          // vector-memory counter (and an LDS-DMA in flight) does not see
 };
 
 #if defined(__HIPCC__)
@@ -140,6 +144,8 @@ struct TransStore {
 // workgroups.  Used once there are at least two 256-pixel workgroups per CU (or forced by MPC_WIDE_BLOCK).
 constexpr int NUM_CU = 256;
 inline bool wide_blocks(const Params &p, int launches_per_pixel_block) {
+    static const bool narrow = [] { const char *e = getenv("MPC_NARROW_BLOCKS"); return e && atoi(e) != 0; }();   // development switch
+    if (narrow) return false;
     return (p.flags & MPC_WIDE_BLOCK) || (p.P + 255) / 256 * launches_per_pixel_block >= 2 * NUM_CU;
 }
 
@@ -162,6 +168,8 @@ struct mpc_conv {
     float *bias = nullptr, *beta = nullptr;
     void *gamma = nullptr;
     int2 *taps = nullptr;
+    int2 taps_host[MAX_TAPS] = {};   // host copy of the tap table (all phases)
+    int ntaps_total = 0;
 };
 
 // f16 path (conv_igemm_f16.hip)

@@ -562,6 +562,9 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         }
     }
     c->nphase = pd.nphase;
+    MPC_REQUIRE(ctx, ntap_total <= MAX_TAPS, "conv_create: too many taps");   // (cannot trigger: at most 25)
+    c->ntaps_total = ntap_total;
+    for (int t = 0; t < ntap_total; ++t) c->taps_host[t] = pd.taps[t];
     int64_t w_total = 0;
     for (int ph = 0; ph < pd.nphase; ++ph) {
         pd.nchunks[ph] = cin4 ? (pd.ntaps[ph] + 7) / 8 : pd.ntaps[ph] * (d.cin / (f16 ? 64 : 32));
@@ -721,6 +724,7 @@ static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, in
     p.cin_blocks = c->cin4 ? 1 : d.cin / 32;
     p.cout = d.cout; p.act = d.act; p.flags = (flags & ~MPC_OUT_ROUND) | (d.flags & MPC_IN_ABS);
     for (int i = 0; i < c->nphase; ++i) p.ph[i] = c->ph[i];
+    for (int t = 0; t < c->ntaps_total; ++t) p.tapv[t] = c->taps_host[t];
     MPC_REQUIRE(ctx, (int64_t)B * H * W * p.Cs < (1ll << 40), "conv_forward: input too large");
 
     p.w_group = c->w_group;

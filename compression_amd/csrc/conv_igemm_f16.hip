@@ -42,7 +42,6 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
     const int tid = threadIdx.x;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const Phase ph = p.ph[blockIdx.y];
-    const int2 *taps = p.taps + ph.tap_off;
 
     const int64_t blk = xcd_block();
     if (blk * (32 * NW) >= p.P) return;                 // padding block of the rounded-up grid
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_igemm_f16_kernel(const Params
     auto load_b = [&](int chunk, float4 (&dst)[4]) {
         int tap = chunk / p.cin_blocks;
         int cb = chunk - tap * p.cin_blocks;
-        int2 d = taps[tap];
+        int2 d = p.tapv[ph.tap_off + tap];                // uniform index: a scalar load from the kernel arguments
         int iy = by * p.sy + d.x, ix = bx * p.sx + d.y;
         bool ok = pvalid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
         const _Float16 *src = in_b + ((int64_t)iy * p.Wi + ix) * p.Cs + cb * 64 + 8 * h;
