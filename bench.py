@@ -57,14 +57,15 @@ CONFIGS = {
             what="JDC full codec on 8 noisy 1024x1024 images"),
 }
 # sources whose change invalidates the committed counter passes of the dominant kernel
-TRAFFIC_SOURCES = ("compression_amd/csrc/conv_igemm_x3.hip", "compression_amd/csrc/conv_common.h")
+TRAFFIC_SOURCES = ("compression_amd/csrc/conv5s2_patch_x3.hip", "compression_amd/csrc/conv_x3_epilogue.h",
+                   "compression_amd/csrc/conv_common.h")
 PMC_TABLE = os.path.join(REPO, "profiles", "r2_pmc_counters.csv")
 PMC_META = os.path.join(REPO, "profiles", "r2_pmc_meta.json")
 
 
 def kernel_peak(name):
     """(peak TFLOP/s of the MFMA type the kernel issues, MFMA instructions issued per algorithmic product)."""
-    if name.startswith("conv_igemm_x3"):
+    if name.startswith("conv_igemm_x3") or name.startswith("conv5s2_patch_x3"):
         return PEAK_F16_MFMA_TFLOPS, 3        # a = hi + lo: three fp16 MFMAs per product
     if name.startswith("conv_igemm_f16"):
         return PEAK_F16_MFMA_TFLOPS, 1
@@ -438,7 +439,7 @@ def run_rank(args):
             dist.destroy_process_group()
         return 0
     value = world * mp_per_step * args.steps / dt
-    conv = [k for k in kern if k.startswith("conv_igemm")]
+    conv = [k for k in kern if k.startswith("conv")]
     dom = max(conv, key=lambda k: kern[k]["ms"])
     d = kern[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -538,8 +538,13 @@ class ConvLayer:
         self._name_fmt = ("conv_igemm_x3_kernel<%d, %d, %s, %%d>" % (nf, epi, "true" if cin <= 4 else "false")) if x3 else \
             ("conv_igemm_f16_kernel<%d, %d, %%d>" % (nf, epi)) if f16 else \
             ("conv_igemm_kernel<%d, %s, %d>" % (nf, "true" if cin <= 4 else "false", epi))
+        # f16x3 5x5 stride-2 layers with cin > 4 run on the LDS-patch kernel (same conditions as the library's dispatch)
+        self._patch = x3 and cin > 4 and kind == _lib.MPC_CONV and ksize == 5 and stride == 2 and cin % 32 == 0 and nf in (4, 6) \
+            and (not gdn or in_bound > 0.0)
+        if self._patch:
+            self._name_fmt = "conv5s2_patch_x3_kernel<%d, %d, 8>" % (nf, epi)
         self._launches = (tiles // nf) * (4 if (kind == _lib.MPC_DECONV and stride == 2 and not self.small_cout) else 1)
-        self.kernel_name = self._name_fmt % 4 if (x3 or f16) else self._name_fmt
+        self.kernel_name = self._name_fmt if (self._patch or not (x3 or f16)) else self._name_fmt % 4
         # the fp16 last layer (cout <= 4) has a kernel of its own
         self._rgb16 = f16 and self.small_cout and cout <= 4 and cin % 64 == 0 and cin <= 256
         ctx = context_for(w.device)
@@ -581,7 +586,7 @@ class ConvLayer:
             # mirrors the library's choice of waves per workgroup (for the kernel name in profiles)
             base = B * (H * W if self.kind == _lib.MPC_DECONV else Ho * Wo)
             wide = (wide_block or -(-base // 256) * self._launches >= 512) and not self.small_cout
-            self.kernel_name = "deconv_rgb16_kernel" if self._rgb16 else self._name_fmt % (8 if wide else 4)
+            self.kernel_name = "deconv_rgb16_kernel" if self._rgb16 else self._name_fmt if self._patch else self._name_fmt % (8 if wide else 4)
         if out_split:
             shape, odt = (B, Ho, Wo, self.cout // 8, 16), torch.float16
         else:
@@ -615,7 +620,7 @@ class ConvLayer:
         if n_clamped is None:
             n_clamped = torch.empty(1, dtype=torch.int32, device=x.device)
         _dev(n_clamped, torch.int32, "n_clamped")
-        if self.x3:
+        if self.x3 and not self._patch:
             base = B * Ho * Wo
             wide = -(-base // 256) * self._launches >= 512
             self.kernel_name = self._name_fmt % (8 if wide else 4)
