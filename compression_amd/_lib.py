@@ -58,6 +58,8 @@ SIGNATURES = {
     "mpc_renorm_cast_cdf": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "mpc_bits_lut": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mpc_prior_argmin": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mpc_prior_bits_network": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "mpc_gather_cdf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mpc_rans_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "mpc_rans_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int,

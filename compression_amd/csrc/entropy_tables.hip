@@ -148,6 +148,70 @@ __global__ void prob_bits_kernel(const float *__restrict__ hi, const float *__re
     }
 }
 
+// ---- network-form prior competition ---------------------------------------------------------------------------
+// bits[k][loc] = sum_c clamp(-log2(P_kc(v + .5) - P_kc(v - .5) + 1e-10), 0, 50) with v = y[loc][c] (+ noise[loc][c]):
+// the K priors' Bitparm chains evaluated at the latent itself, which need not be an integer (training-mode forward:
+// uniform-noise quantisation, src/compression/models/manynets_compressor.py:514-530, 547-554).  One wavefront per
+// location, lane k = prior k; the channel sum keeps the association of ATen's sum over dim 2 of the [K,B,M,h,w]
+// tensor (16 sequential adds into a level-0 accumulator, drained into level 1, every 256 channels into level 2), and
+// the minimum follows torch.min (NaN wins, ties go to the lower index).
+struct Cand {
+    float v;
+    int k;
+};
+__device__ __forceinline__ Cand better(Cand a, Cand b) {
+    bool an = a.v != a.v, bn = b.v != b.v;
+    bool a_wins;
+    if (an || bn) a_wins = (an && bn) ? (a.k < b.k) : an;
+    else a_wins = (a.v < b.v) || (a.v == b.v && a.k < b.k);
+    return a_wins ? a : b;
+}
+
+__global__ __launch_bounds__(256) void prior_bits_network_kernel(const float *__restrict__ prep, int K, int M,
+                                                                  const float *__restrict__ y, const float *__restrict__ noise,
+                                                                  int64_t n_loc, float *__restrict__ y_entropy,
+                                                                  float *__restrict__ total_bits, int32_t *__restrict__ idx,
+                                                                  float *__restrict__ minbits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t loc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (loc >= n_loc) return;
+    const bool active = lane < K;
+    const float *prow = prep + (int64_t)(active ? lane : 0) * M * PREP;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
+    for (int c = 0; c < M; ++c) {
+        float v = y[loc * M + c];
+        if (noise) v = __fadd_rn(v, noise[loc * M + c]);
+        if (y_entropy && lane == 0) y_entropy[loc * M + c] = v;
+        const float *p = prow + (int64_t)c * PREP;
+        float pr = __fsub_rn(bitparm_chain(__fadd_rn(v, 0.5f), p), bitparm_chain(__fsub_rn(v, 0.5f), p));
+        acc0 = __fadd_rn(acc0, code_length(pr, MPC_BITS_LOG2));
+        if (((c + 1) & 15) == 0 && c + 1 <= (M & ~15)) {
+            acc1 = __fadd_rn(acc1, acc0);
+            acc0 = 0.0f;
+            if (((c + 1) & 0xF0) == 0) {
+                acc2 = __fadd_rn(acc2, acc1);
+                acc1 = 0.0f;
+            }
+        }
+    }
+    float total = __fadd_rn(__fadd_rn(acc0, acc1), acc2);
+    if (total_bits && active) total_bits[(int64_t)lane * n_loc + loc] = total;
+    Cand best;
+    best.v = active ? total : __builtin_inff();
+    best.k = active ? lane : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Cand o;
+        o.v = __shfl_xor(best.v, off, 64);
+        o.k = __shfl_xor(best.k, off, 64);
+        best = better(best, o);
+    }
+    if (lane == 0) {
+        if (idx) idx[loc] = best.k;
+        if (minbits) minbits[loc] = best.v;
+    }
+}
+
 __global__ void laplace_rows_kernel(const float *__restrict__ sigma, int64_t n, float first, int L, float factor,
                                     int16_t *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,6 +262,21 @@ int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_
     if (rc) return rc;
     bitparm_eval_kernel<<<dim3(blocks_for(n_rows * n_per_row)), dim3(256), 0, ctx->stream>>>(prep, n_rows, x, n_per_row, row_minor, offset, out);
     MPC_CHECK_LAUNCH(ctx, "bitparm_eval");
+    MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
+    return MPC_OK;
+}
+
+int mpc_prior_bits_network(mpc_ctx *ctx, const float *const params[11], int K, int M, const float *y, const float *noise,
+                           int64_t n_loc, float *y_entropy, float *total_bits, int32_t *idx, float *minbits) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, params && y && n_loc > 0 && M > 0 && K > 0 && K <= 64 && (total_bits || idx || minbits),
+                "prior_bits_network: bad arguments (K must be 64 or less)");
+    float *prep = nullptr;
+    int rc = make_prep(ctx, params, (int64_t)K * M, &prep);
+    if (rc) return rc;
+    prior_bits_network_kernel<<<dim3((unsigned)mpc_cdiv(n_loc, 4)), dim3(256), 0, ctx->stream>>>(prep, K, M, y, noise, n_loc, y_entropy,
+                                                                                                 total_bits, idx, minbits);
+    MPC_CHECK_LAUNCH(ctx, "prior_bits_network");
     MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
     return MPC_OK;
 }

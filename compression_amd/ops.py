@@ -242,6 +242,25 @@ def prior_argmin(sym: torch.Tensor, lut: torch.Tensor, want_total: bool = False)
     return idx, minbits, total
 
 
+def prior_bits_network(params: Sequence[torch.Tensor], y: torch.Tensor, K: int, noise: Optional[torch.Tensor] = None,
+                       want_entropy_latent: bool = False):
+    """The competition in its network form (latents that need not be integers): y fp32 [n_loc, M] (NHWC), params the 11
+    Bitparm tensors of the K heads ([K,1,M,1,1] each), noise (optional) of y's shape is added first.
+    -> (idx int32 [n_loc], minbits fp32 [n_loc], total fp32 [K, n_loc], y + noise | None)."""
+    _dev(y, torch.float32, "y")
+    n_loc, M = y.shape
+    if noise is not None and _dev(noise, torch.float32, "noise").shape != y.shape:
+        raise MpcError("prior_bits_network: noise must have the latent's shape")
+    arr, keep = _param_array(params, K * M)
+    idx = torch.empty(n_loc, dtype=torch.int32, device=y.device)
+    minbits = torch.empty(n_loc, dtype=torch.float32, device=y.device)
+    total = torch.empty((K, n_loc), dtype=torch.float32, device=y.device)
+    ye = torch.empty_like(y) if want_entropy_latent else None
+    context_for(y.device).call("mpc_prior_bits_network", arr, K, M, ptr(y), ptr(noise), n_loc, ptr(ye), ptr(total), ptr(idx),
+                               ptr(minbits))
+    return idx, minbits, total, ye
+
+
 def gather_cdf(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """table int16 [K,M,L], idx int32 [n_loc] -> int16 [n_loc, M, L] (written into `out` when given)."""
     _dev(table, torch.int16, "table")

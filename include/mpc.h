@@ -147,6 +147,14 @@ int mpc_bits_lut(mpc_ctx *ctx, const float *table_f, int K, int M, int L, int fo
  * manynets_compressor.py:548-554 and :238-249.  K must be 64 or less. */
 int mpc_prior_argmin(mpc_ctx *ctx, const int16_t *sym, int64_t n_loc, int M, int K, int S,
                      const float *lut, int32_t *idx, float *minbits, float *total_bits);
+/* The same competition in its network form, for latents that are not integers: total[k] = sum_c
+ * clamp(-log2(P_kc(v + .5) - P_kc(v - .5) + 1e-10), 0, 50) with v = y[loc][c] (+ noise[loc][c] when noise is given),
+ * the Bitparm chains of params[11] (K*M rows, row = k*M + c) evaluated at v itself.  y and noise are [n_loc][M] fp32
+ * (NHWC); y_entropy (may be NULL) receives v; total_bits [K][n_loc], idx, minbits as in mpc_prior_argmin (each may be
+ * NULL).  Training-mode forward: manynets_compressor.py:514-530 (uniform-noise quantisation) and :547-554. */
+int mpc_prior_bits_network(mpc_ctx *ctx, const float *const params[11], int K, int M, const float *y,
+                           const float *noise, int64_t n_loc, float *y_entropy, float *total_bits, int32_t *idx,
+                           float *minbits);
 
 /* ---- per-symbol CDF rows ("CDF build") ------------------------------------------------------ */
 /* out[loc][c][:] = table[idx[loc]][c][:]   (int16 [n_loc][M][L]).  manynets_compressor.py:252-262,

@@ -330,6 +330,44 @@ def manypriors_forward(x: torch.Tensor, sd: SD, min_feat: int = -127, use_lut: b
     }
 
 
+def manypriors_forward_train(x: torch.Tensor, sd: SD, noise: torch.Tensor, passthrough_ae: bool,
+                             dists_last_use: np.ndarray, synthesis_fn=synthesis) -> dict:
+    """Training-mode forward of the Manypriors model (values only), dist_patch_size == 1.
+    manynets_compressor.py:514-530 (noise quantisation; passthrough_ae: the decoder sees round(y)), :547-561
+    (network-form bits on the noisy latent), :579-602 (prior bookkeeping, forced training of priors idle for more
+    than 50 calls; draws from numpy's global generator like the reference), :604-607, :621-625.
+    `noise` is the U(-0.5, 0.5) tensor the reference draws; `dists_last_use` is updated in place."""
+    K = sd["bitEstimators.f1.h"].shape[0]
+    y = analysis(x, sd)
+    y_entropy = y + noise
+    y_ae = torch.round(y) if passthrough_ae else y_entropy
+    recon = synthesis_fn(y_ae, sd)
+    total = prior_bits_network(y_entropy, sd)
+    minbits, idx = total.min(0)
+    max_forced = int(y_entropy.size(0) * y_entropy.size(2) * y_entropy.size(3) * 0.1)
+    used = idx.unique()
+    dists_last_use[used.numpy()] = 0
+    unused = np.setdiff1d(np.arange(K), used.numpy(), assume_unique=True)
+    dists_last_use[unused] += 1
+    num_forced = 0
+    if K > 1:
+        idle = np.argwhere(dists_last_use > 50).flatten()
+        num_forced = min(idle.size, max_forced)
+        victims = minbits.flatten().sort(descending=True).indices[:num_forced]
+        idx.flatten()[victims] = torch.tensor(np.random.choice(unused, victims.size(), replace=False))
+    npix = x.shape[0] * x.shape[2] * x.shape[3]
+    bits_feature = torch.gather(total, 0, idx.unsqueeze(0)).sum()
+    # the reference charges feature_batched_shape[0] = the BATCH size (not the location count) times log2 K here
+    bpp_side = torch.tensor((y_entropy.size(0) * math.log2(K)) / npix)
+    bpp_feature = bits_feature / npix
+    return {
+        "y": y, "recon": recon, "reconstructed_image": recon.clamp(0.0, 1.0), "visual_loss": F.mse_loss(recon, x),
+        "total_bits": total, "minbits": minbits, "idx": idx,
+        "bpp_feature": bpp_feature, "bpp_sidestring": bpp_side, "bpp": bpp_feature + bpp_side,
+        "used_dists": used.tolist(), "num_forced_dists": num_forced,
+    }
+
+
 def prior_bits_lut_encode_layout(yhat: torch.Tensor, table_f: torch.Tensor, min_feat: int = -127):
     """LUT competition exactly as encode() lays it out: bits as a [K, h*w, M, 1] tensor summed over
     dim 2 (manynets_compressor.py:238-249).  ATen reduces this contiguous inner dimension in a

@@ -103,9 +103,55 @@ def metrics_fixture():
     print({k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
 
 
+TRAIN_CASES = (("pt", True, 71), ("noisy", False, 72))     # (tag, passthrough_ae, seed)
+
+
+def train_inputs(seed):
+    """Input batch and the idle-prior counters of the training-mode fixture: priors 3, 17 and 40 have been idle for 60
+    calls, so the forward must force them onto the most expensive locations."""
+    x = synth.smooth_image(seed, 2, 64, 96)
+    last_use = np.zeros(64, dtype=int)
+    last_use[[3, 17, 40]] = 60
+    return x, last_use
+
+
+def train_fixture():
+    """Training-mode forward of the reference (manynets_compressor.py:514-530, 586-602) on seeded noise."""
+    mc, am, b18, tc = import_reference()
+    cpu = torch.device("cpu")
+    torch.set_grad_enabled(False)
+    N, M, K = 192, 256, 64
+    sd = synth.manypriors_state_dict(234, N, M, K, spread=True)
+    out = {}
+    for tag, passthrough, seed in TRAIN_CASES:
+        m = load(mc.Balle2017ManyPriors_ImageCompressor(out_channel_N=N, out_channel_M=M, num_distributions=K,
+                                                        device=cpu, passthrough_ae=passthrough), sd)
+        m.train(True)
+        x, last_use = train_inputs(seed)
+        m.dists_last_use[:] = last_use
+        # the forward's first draw from torch's generator is the quantisation noise: the same seed and the same call
+        # reproduce it
+        torch.manual_seed(seed)
+        noise = torch.nn.init.uniform_(torch.zeros(x.shape[0], M, x.shape[2] // 16, x.shape[3] // 16), -0.5, 0.5)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        res = m(x)
+        out.update({
+            f"{tag}_noise": noise.numpy(), f"{tag}_xhat": res["reconstructed_image"].numpy(),
+            f"{tag}_visual_loss": float(res["visual_loss"]), f"{tag}_bpp_feature": float(res["bpp_feature"]),
+            f"{tag}_bpp_sidestring": float(res["bpp_sidestring"]), f"{tag}_bpp": float(res["bpp"]),
+            f"{tag}_used_dists": np.array(res["used_dists"]), f"{tag}_num_forced": np.array(res["num_forced_dists"]),
+            f"{tag}_last_use_after": m.dists_last_use.copy(),
+        })
+    np.savez_compressed(os.path.join(OUT, "forward_train.npz"), **out)
+    print({k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         return metrics_fixture()
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        return train_fixture()
     mc, am, b18, tc = import_reference()
     cpu = torch.device("cpu")
     torch.set_grad_enabled(False)
