@@ -67,7 +67,7 @@ def kernel_peak(name):
     """(peak TFLOP/s of the MFMA type the kernel issues, MFMA instructions issued per algorithmic product)."""
     if name.startswith("conv_igemm_x3") or name.startswith("conv5s2_patch_x3"):
         return PEAK_F16_MFMA_TFLOPS, 3        # a = hi + lo: three fp16 MFMAs per product
-    if name.startswith("conv_igemm_f16"):
+    if name.startswith("conv_igemm_f16") or name.startswith("deconv5s2_patch_f16"):
         return PEAK_F16_MFMA_TFLOPS, 1
     return PEAK_F32_MFMA_TFLOPS, 1
 
@@ -439,7 +439,7 @@ def run_rank(args):
             dist.destroy_process_group()
         return 0
     value = world * mp_per_step * args.steps / dt
-    conv = [k for k in kern if k.startswith("conv")]
+    conv = [k for k in kern if k.startswith("conv") or k.startswith("deconv5s2")]
     dom = max(conv, key=lambda k: kern[k]["ms"])
     d = kern[dom]
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

@@ -33,8 +33,6 @@ constexpr int ROW_F4 = 2 * 4 * X2;                  // 144 slots = 2304 bytes pe
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
 
-// s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
-#define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
 template <int NF, int EPI, int TR>
 __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Params p) {

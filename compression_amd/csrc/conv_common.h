@@ -19,6 +19,8 @@ enum { EPI_PLAIN = 0, EPI_GDN = 1, EPI_STACKED = 2 };
 // input taps, then meet in one L2 instead of being fetched by all eight.
 constexpr int NUM_XCD = 8;
 inline int64_t xcd_grid(int64_t blocks) { return (blocks + NUM_XCD - 1) / NUM_XCD * NUM_XCD; }
+// s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
+#define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 #if defined(__HIPCC__)
 __device__ __forceinline__ int64_t xcd_block() {
     const unsigned per = gridDim.x / NUM_XCD;
@@ -64,6 +66,7 @@ struct Params {
     float sym_min_feat;   // symbol = rint(out) - sym_min_feat, clamped to [0, sym_max]
     int sym_max;
     int *n_clamped;       // number of symbols that had to be clamped (may be null)
+    const void *zeros;    // 256 bytes of zeros (what a tap outside the image reads)
     Phase ph[MAX_PHASES];
     int2 tapv[MAX_TAPS];  // the tap table by value: indexed with a uniform index it is read by scalar loads, which the
                           // vector-memory counter (and an LDS-DMA in flight) does not see
@@ -165,7 +168,7 @@ struct mpc_conv {
     int sy, sx, my, mx;
     Phase ph[MAX_PHASES];
     void *wpk = nullptr;
-    float *bias = nullptr, *beta = nullptr;
+    float *bias = nullptr, *beta = nullptr;   // bias: nf*groups*32 floats, followed by 64 floats of zeros
     void *gamma = nullptr;
     int2 *taps = nullptr;
     int2 taps_host[MAX_TAPS] = {};   // host copy of the tap table (all phases)
@@ -179,6 +182,9 @@ bool mpc_conv_rgb16_supported(int cin, int cout);
 size_t mpc_conv_rgb16_image_bytes(int cin);
 hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *image, hipStream_t stream);
 int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
+// fp16 5x5 stride-2 transposed convolutions with the input patch staged in LDS (deconv5s2_patch_f16.hip)
+bool mpc_deconv_patch_f16_supported(const Params &p, const mpc_conv *c);
+int mpc_deconv_launch_patch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // split-fp16 path (conv_igemm_x3.hip)
 int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // split-fp16 5x5 stride-2 layers with the input patch staged in LDS (conv5s2_patch_x3.hip)

@@ -586,10 +586,10 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         return MPC_EHIP;
     };
     if ((e = hipMalloc((void **)&c->wpk, ((f16 || x3) ? sizeof(_Float16) : sizeof(float)) * w_total)) != hipSuccess) return fail("hipMalloc(weights)");
-    if ((e = hipMalloc((void **)&c->bias, sizeof(float) * nf * groups * 32)) != hipSuccess) return fail("hipMalloc(bias)");
+    if ((e = hipMalloc((void **)&c->bias, sizeof(float) * (nf * groups * 32 + 64))) != hipSuccess) return fail("hipMalloc(bias)");
     if ((e = hipMalloc((void **)&c->taps, sizeof(int2) * ntap_total)) != hipSuccess) return fail("hipMalloc(taps)");
     if ((e = hipMemcpyAsync(c->taps, pd.taps, sizeof(int2) * ntap_total, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail("copy taps");
-    if ((e = hipMemsetAsync(c->bias, 0, sizeof(float) * nf * groups * 32, ctx->stream)) != hipSuccess) return fail("memset bias");
+    if ((e = hipMemsetAsync(c->bias, 0, sizeof(float) * (nf * groups * 32 + 64), ctx->stream)) != hipSuccess) return fail("memset bias");
     if ((e = hipMemcpyAsync(c->bias, bias, sizeof(float) * d.cout, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess) return fail("copy bias");
     if (x3) {
         // per-layer power-of-two weight scale: max |w| * scale in [2^13, 2^14)
@@ -716,6 +716,7 @@ static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, in
     mpc_conv_out_hw(c, H, W, &Ho, &Wo);
     p.in = in; p.out = out; p.out_round = want_round ? out_round : nullptr;
     p.out_sym = sym; p.sym_min_feat = (float)min_feat; p.sym_max = n_sym_values - 1; p.n_clamped = n_clamped_dev;
+    p.zeros = c->bias + c->nf * c->groups * 32;
     p.wpk = c->wpk; p.bias = c->bias; p.beta = c->beta; p.gamma = c->gamma; p.taps = c->taps;
     p.B = B; p.Hi = H; p.Wi = W; p.Cs = c->cin4 ? 4 : d.cin;
     p.Ho = Ho; p.Wo = Wo; p.sy = c->sy; p.sx = c->sx; p.my = c->my; p.mx = c->mx;

@@ -252,6 +252,10 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase) {
 
 int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
+    if (mpc_deconv_patch_f16_supported(p, c)) {
+        static const bool off = [] { const char *e = getenv("MPC_F16_PATCH"); return e && atoi(e) == 0; }();   // development switch
+        if (!off) return mpc_deconv_launch_patch_f16(ctx, p, c);
+    }
     if (c->stacked) return c->wpk_rgb16 ? mpc_conv_launch_rgb16(ctx, p, c) : launch<1, EPI_STACKED>(ctx, p, c->nphase);
     if (gdn) {
         if (c->nf == 4) return launch<4, EPI_GDN>(ctx, p, c->nphase);

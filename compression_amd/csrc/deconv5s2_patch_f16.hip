@@ -1,0 +1,349 @@
+// fp16 5x5 stride-2 transposed convolution (the three big layers of the synthesis transform, fused IGDN) with the
+// input staged through LDS as a 2-D patch and every global -> LDS transfer done by LDS-DMA.
+//
+// Why.  A stride-2 transposed convolution is four stride-1 problems on the input grid, one per output parity, with
+// 9 / 6 / 6 / 4 taps whose offsets lie in [-1, 1]^2.  In the register-gather kernel (conv_igemm_f16.hip) every lane
+// fetches its own pixel's 16 bytes per k-step and tap: one wave-instruction touches 32 cache lines and uses 32 bytes
+// of each, and that gather (not the MFMAs, not LDS) paces the K loop -- in-kernel timestamps put the K loop at 43 % of
+// the MFMA rate, and the stretch scales with the number of such loads.  Here a workgroup owns a 16 x 8 tile of input
+// pixels and keeps the 18 x 10 patch around it, 32 input channels at a time, in LDS: the patch is fetched once per
+// channel block in whole 64-byte runs (1.4x the tile's bytes, the halo) and all taps read it with ds_read_b128.
+//
+// K walk: for each 32-channel block, the taps of this workgroup's phase.  One step = one tap x 32 channels = two
+// k-steps of v_mfma_f32_32x32x16_f16 over the wave's NF output tiles (a wave = 2 tile rows = 32 pixels x all output
+// channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
+// streamed by LDS-DMA through a ring of three half chunks, two steps ahead; the next channel block's patch is brought
+// by LDS-DMA into the other patch buffer during the first steps of the current block.  No transfer passes through
+// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one counted s_waitcnt, one s_barrier.
+//
+// LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
+// one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
+// all 64 banks, and a row pitch of 1536 bytes (a multiple of the 256-byte bank row) keeps the two tile rows that share
+// a ds_read_b128 lane group on distinct slots.  Padding slots are filled too (from a page of zeros): a DMA piece is
+// 64 consecutive slots whatever they hold.
+//
+// Two workgroups of four waves per CU (80 KB of LDS each): their barriers and epilogues fall out of phase, so one's
+// MFMAs cover the other's waits and stores.  Same operand formats, GDN continuation and output path as
+// conv_igemm_f16.hip; the K axis is summed in another order (channel block major), so results agree with it to fp32
+// rounding, not bit for bit.
+#include <type_traits>
+
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float SQ_SCALE = 0.00390625f;      // 2^-8
+constexpr float SQ_UNSCALE = 256.0f;
+constexpr float HALF_MAX = 65504.0f;
+
+constexpr int TILE_W = 16, TILE_H = 8, NW = 4, NT = 64 * NW;
+constexpr int PATCH_COLS = TILE_W + 2, PATCH_ROWS = TILE_H + 2;
+constexpr int PIX_F4 = 5;                            // slots per patch pixel (4 data + 1 padding)
+constexpr int ROW_F4 = 96;                           // slots per patch row (18 x 5 = 90 + 6 padding)
+constexpr int PATCH_PIECES = 16;                     // 1 KB DMA pieces per patch buffer (10 x 96 = 960 slots, rounded up)
+constexpr int PATCH_F4 = PATCH_PIECES * 64;
+constexpr int PPW = PATCH_PIECES / NW;               // patch pieces per wave
+
+__device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
+__device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -HALF_MAX), HALF_MAX); }
+
+// patch pieces issued in step `tap` of a block with NTAPS taps: all PPW pieces go out in the first NTAPS - 2 steps
+// (a piece may stay in flight for two steps, and the block's last step must find the next patch complete)
+template <int NTAPS>
+__host__ __device__ constexpr int pieces_in_step(int tap) {
+    constexpr int per = (PPW + (NTAPS - 2) - 1) / (NTAPS - 2);
+    const int first = tap * per;
+    return tap < 0 ? 0 : (first >= PPW ? 0 : (first + per > PPW ? PPW - first : per));
+}
+
+template <int NF, int EPI>
+struct Body {
+    static constexpr int COUT = NF * 32;
+    static constexpr int WCH_F4 = COUT * 4;              // slots of a half chunk (1 tap x 32 channels): [ks 2][h 2][cout]
+    static constexpr int WPW = WCH_F4 / 64 / NW;         // 1 KB pieces of a half chunk that each wave brings
+    static_assert(WPW * NW * 64 == WCH_F4, "a half chunk must split evenly into 1 KB pieces per wave");
+
+    template <int NTAPS>
+    static __device__ __forceinline__ void run(const Params &p, const Phase &ph, f4 *lds) {
+        f4 *patch = lds;                                 // 2 x PATCH_F4
+        f4 *wring = lds + 2 * PATCH_F4;                  // 3 x WCH_F4
+
+        const int tid = threadIdx.x;
+        const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+
+        const int tiles_x = (p.Wb + TILE_W - 1) / TILE_W, tiles_y = (p.Hb + TILE_H - 1) / TILE_H;
+        const int64_t blk = xcd_block();
+        if (blk >= (int64_t)p.B * tiles_y * tiles_x) return;     // padding block of the rounded-up grid
+        const int b = (int)(blk / (tiles_y * tiles_x));
+        const int trem = (int)(blk - (int64_t)b * tiles_y * tiles_x);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int by = ty * TILE_H + 2 * wave + (j >> 4), bx = tx * TILE_W + (j & 15);
+        const bool pvalid = by < p.Hb && bx < p.Wb;
+
+        // ---- patch staging: slot s of the LDS image <- 16 bytes of the input (or of the zero page) ------------
+        const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs;
+        const int iy0 = ty * TILE_H - 1, ix0 = tx * TILE_W - 1;
+        int soff[PPW];                                   // element offset inside the image, -1 = zeros
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int s = (wave * PPW + i) * 64 + lane;
+            const int r = s / ROW_F4, rem = s - r * ROW_F4;
+            const int c = rem / PIX_F4, part = rem - c * PIX_F4;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = r < PATCH_ROWS && c < PATCH_COLS && part < 4 && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            soff[i] = ok ? (iy * p.Wi + ix) * p.Cs + part * 8 : -1;
+        }
+        const _Float16 *zeros = (const _Float16 *)p.zeros;
+        auto dma_patch = [&](int i, int cb, int buf) {   // piece i of this wave, channel block cb, into patch buffer buf
+            const _Float16 *src = soff[i] >= 0 ? in_b + soff[i] + cb * 32 : zeros;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(patch + buf * PATCH_F4 + (wave * PPW + i) * 64),
+                                             16, 0, 0);
+        };
+
+        // ---- weights: half chunk (tap, cb) of the packed image, then gamma's half chunks, by LDS-DMA ------------
+        const int ncb = p.Cs / 32;                       // 32-channel blocks
+        const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + ph.w_off);
+        const f4 *gsrc = (const f4 *)p.gamma;
+        // packed order: chunk (tap, 64-channel block) at (tap * ncb/2 + cb/2) full chunks, its halves 12 KB apart
+        auto w_half = [&](int tap, int cb) -> const f4 * {
+            return wsrc + ((int64_t)(tap * (ncb >> 1) + (cb >> 1)) * 2 + (cb & 1)) * WCH_F4;
+        };
+        auto dma_w = [&](const f4 *src, int slot) {
+#pragma unroll
+            for (int q = 0; q < WPW; ++q) {
+                const int piece = wave * WPW + q;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
+                                                 (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
+            }
+        };
+
+        f32x16 acc[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+        // prologue: weights of steps 0 and 1, patch of block 0
+        dma_w(w_half(0, 0), 0);
+        dma_w(w_half(1, 0), 1);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
+        MPC_WAIT_VMCNT(0);
+        __syncthreads();
+
+        // this lane's pixel in the patch (tap (0,0) is patch row + 1, column + 1), piece h of each k-step
+        const int lane_slot = (2 * wave + (j >> 4) + 1) * ROW_F4 + ((j & 15) + 1) * PIX_F4 + h;
+        int slot = 0;                                    // ring slot of the current half chunk; step + 2 goes to slot + 2 (mod 3)
+        int pbuf = 0;
+
+        // one step: tap TAP of the current 32-channel block
+        auto step = [&](auto tap_c, int cb, bool more) {
+            constexpr int TAP = decltype(tap_c)::value;
+            // weights two steps ahead: (TAP + 2, cb), or in the next block, or gamma's first half chunks
+            const f4 *nsrc = (TAP + 2 < NTAPS) ? w_half(TAP + 2, cb)
+                             : more            ? w_half(TAP + 2 - NTAPS, cb + 1)
+                             : (EPI == EPI_GDN) ? gsrc + (int64_t)(TAP + 2 - NTAPS) * WCH_F4
+                                                : wsrc;
+            dma_w(nsrc, slot >= 1 ? slot - 1 : 2);
+            // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
+            constexpr int first = TAP * ((PPW + (NTAPS - 2) - 1) / (NTAPS - 2));
+#pragma unroll
+            for (int i = 0; i < pieces_in_step<NTAPS>(TAP); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
+
+            const int2 d = p.tapv[ph.tap_off + TAP];     // uniform index: a scalar load from the kernel arguments
+            const f4 *bp = patch + pbuf * PATCH_F4 + lane_slot + d.x * ROW_F4 + d.y * PIX_F4;
+            const f4 *wl = wring + slot * WCH_F4 + h * COUT + j;
+            const half8 b0 = as_half8(bp[0]), b1 = as_half8(bp[2]);
+            half8 a[2][NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) a[0][f] = as_half8(wl[f * 32]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) a[1][f] = as_half8(wl[2 * COUT + f * 32]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
+            // order of the step: the operands of the first k-step, the second k-step's reads in front of the first's MFMAs
+#ifdef MPC_DP_GROUPS
+            __builtin_amdgcn_sched_group_barrier(0x100, NF + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
+#endif
+            // all but this step's transfers and the previous step's patch pieces have landed: the next step's weights
+            // (issued one step ago, before that step's patch pieces) among them
+            MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            slot = slot == 2 ? 0 : slot + 1;
+        };
+
+        for (int cb = 0; cb < ncb; ++cb) {
+            const bool more = cb + 1 < ncb;
+            step(std::integral_constant<int, 0>{}, cb, more);
+            step(std::integral_constant<int, 1>{}, cb, more);
+            step(std::integral_constant<int, 2>{}, cb, more);
+            step(std::integral_constant<int, 3>{}, cb, more);
+            if constexpr (NTAPS > 4) {
+                step(std::integral_constant<int, 4>{}, cb, more);
+                step(std::integral_constant<int, 5>{}, cb, more);
+            }
+            if constexpr (NTAPS > 6) {
+                step(std::integral_constant<int, 6>{}, cb, more);
+                step(std::integral_constant<int, 7>{}, cb, more);
+                step(std::integral_constant<int, 8>{}, cb, more);
+            }
+            pbuf ^= 1;
+        }
+
+        // ---- epilogue: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h of pixel (by, bx) --------------------
+        const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 bb = *(const float4 *)(p.bias + 32 * f + 8 * g + 4 * h);
+                acc[f][4 * g + 0] += bb.x;
+                acc[f][4 * g + 1] += bb.y;
+                acc[f][4 * g + 2] += bb.z;
+                acc[f][4 * g + 3] += bb.w;
+            }
+        if constexpr (EPI == EPI_GDN) {
+            const bool inverse = p.act == MPC_ACT_IGDN;
+            // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF more steps: half chunk hc holds gamma[:, 32 hc .. 32 hc + 31]
+            // in the weight layout; the B operand is built from the lane's own accumulators, whose registers 8s..8s+7
+            // of tile hc are the 8 k-values of k-step s (c = 32 hc + 16 s + 8(jj>>2) + 4h + (jj&3)).  y^2 is scaled by
+            // 2^-8 and saturated before the conversion to fp16; the scale is undone on the fp32 sum.
+            f32x16 nrm[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+#pragma unroll
+            for (int hc = 0; hc < NF; ++hc) {
+                dma_w(gsrc + (int64_t)(hc + 2 < NF ? hc + 2 : 0) * WCH_F4, slot >= 1 ? slot - 1 : 2);
+                const f4 *wl = wring + slot * WCH_F4 + h * COUT + j;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    half8 bv;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        float y = acc[hc][8 * s + jj];
+                        bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                    }
+#pragma unroll
+                    for (int fo = 0; fo < NF; ++fo)
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[(s * 2) * COUT + fo * 32]), bv, nrm[fo], 0, 0, 0);
+                }
+                MPC_WAIT_VMCNT(WPW);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            MPC_WAIT_VMCNT(0);                            // the surplus DMA pieces have landed before the LDS is reused
+            __syncthreads();
+            // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
+            // all output channels in one round); v_rsq_f32 is far more accurate than the fp16 output
+            TransStore ts;
+            ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 be = *(const float4 *)(p.beta + 32 * f + 8 * g + 4 * h);
+                    const float bev[4] = {be.x, be.y, be.z, be.w};
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float a = nrm[f][4 * g + t] * SQ_UNSCALE + bev[t];
+                        float rs = __builtin_amdgcn_rsqf(a);
+                        float y = acc[f][4 * g + t];
+                        o[t] = sat_half(inverse ? y * (a * rs) : y * rs);
+                    }
+                    *(half4 *)ts.at(j, f * 64 + (8 * g + 4 * h) * 2) = o;
+                }
+            ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
+        } else {
+            MPC_WAIT_VMCNT(0);                            // no DMA is left in flight when the workgroup ends
+            if (!pvalid) return;
+            _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int c0 = 32 * f + 8 * g + 4 * h;
+                    half4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float v = acc[f][4 * g + t];
+                        if (p.act == MPC_ACT_RELU) v = fmaxf(v, 0.0f);
+                        o[t] = sat_half(v);
+                    }
+                    *(half4 *)(orow + c0) = o;
+                }
+        }
+    }
+};
+
+template <int NF, int EPI>
+__global__ __launch_bounds__(NT, 2) void deconv5s2_patch_f16_kernel(const Params p) {
+    extern __shared__ f4 lds[];
+    const Phase &ph = p.ph[blockIdx.y];
+    switch (ph.ntaps) {                                  // (uniform: the phase is the workgroup's)
+        case 9: Body<NF, EPI>::template run<9>(p, ph, lds); break;
+        case 6: Body<NF, EPI>::template run<6>(p, ph, lds); break;
+        default: Body<NF, EPI>::template run<4>(p, ph, lds); break;
+    }
+}
+
+template <int NF, int EPI>
+int launch(mpc_ctx *ctx, const Params &p, int nphase) {
+    size_t lds = ((size_t)2 * PATCH_F4 + 3 * (size_t)NF * 32 * 4) * sizeof(f4);
+    if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    auto kern = deconv5s2_patch_f16_kernel<NF, EPI>;
+    static bool attr_set[MPC_MAX_DEVICES] = {};
+    bool &attr_done = attr_set[ctx->device];
+    if (!attr_done) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int64_t tiles = (int64_t)p.B * mpc_cdiv(p.Hb, TILE_H) * mpc_cdiv(p.Wb, TILE_W);
+    const int64_t bx = xcd_grid(tiles);
+    MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many tiles");
+    kern<<<dim3((unsigned)bx, (unsigned)nphase, 1), dim3(NT), lds, ctx->stream>>>(p);
+    MPC_CHECK_LAUNCH(ctx, "deconv5s2_patch_f16");
+    return MPC_OK;
+}
+
+}  // namespace
+
+// True when the layer / call can run on the patch kernel: a 5x5 stride-2 transposed convolution on the fp16 path with
+// four parity phases of 9 / 6 / 6 / 4 taps, input channels a multiple of 64, 128 or 192 output channels.
+bool mpc_deconv_patch_f16_supported(const Params &p, const mpc_conv *c) {
+    const mpc_conv_desc &d = c->desc;
+    if (!c->f16 || c->stacked || d.kind != MPC_DECONV || d.ksize != 5 || d.stride != 2 || d.pad != 2) return false;
+    if (d.cin % 64 != 0 || (c->nf != 4 && c->nf != 6) || c->groups != 1 || c->nphase != 4) return false;
+    for (int i = 0; i < c->nphase; ++i) {
+        const int n = c->ph[i].ntaps;
+        if (n != 9 && n != 6 && n != 4) return false;
+    }
+    for (int t = 0; t < c->ntaps_total; ++t)
+        if (abs(c->taps_host[t].x) > 1 || abs(c->taps_host[t].y) > 1) return false;
+    const bool gdn = d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN;
+    if (!gdn && d.act != MPC_ACT_NONE && d.act != MPC_ACT_RELU) return false;
+    if ((int64_t)p.Hi * p.Wi * p.Cs >= (1ll << 31)) return false;        // 32-bit element offsets inside one image
+    return true;
+}
+
+int mpc_deconv_launch_patch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
+    if (gdn && c->nf == 6) return launch<6, EPI_GDN>(ctx, p, c->nphase);
+    if (gdn && c->nf == 4) return launch<4, EPI_GDN>(ctx, p, c->nphase);
+    if (!gdn && c->nf == 6) return launch<6, EPI_PLAIN>(ctx, p, c->nphase);
+    if (!gdn && c->nf == 4) return launch<4, EPI_PLAIN>(ctx, p, c->nphase);
+    MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (fp16 patch kernel): unsupported layer shape (cout/32 = %d)", c->nf);
+}

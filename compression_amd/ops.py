@@ -562,6 +562,12 @@ class ConvLayer:
             and (not gdn or in_bound > 0.0)
         if self._patch:
             self._name_fmt = "conv5s2_patch_x3_kernel<%d, %d, 8>" % (nf, epi)
+        # fp16 5x5 stride-2 transposed convolutions run on their own LDS-patch kernel (the library's dispatch conditions)
+        self._dpatch = f16 and kind == _lib.MPC_DECONV and ksize == 5 and stride == 2 and cin % 64 == 0 and nf in (4, 6) \
+            and not self.small_cout and cout <= 192
+        if self._dpatch:
+            self._patch = True
+            self._name_fmt = "deconv5s2_patch_f16_kernel<%d, %d>" % (nf, epi)
         self._launches = (tiles // nf) * (4 if (kind == _lib.MPC_DECONV and stride == 2 and not self.small_cout) else 1)
         self.kernel_name = self._name_fmt if (self._patch or not (x3 or f16)) else self._name_fmt % 4
         # the fp16 last layer (cout <= 4) has a kernel of its own
