@@ -152,6 +152,77 @@ inline bool wide_blocks(const Params &p, int launches_per_pixel_block) {
     return (p.flags & MPC_WIDE_BLOCK) || (p.P + 255) / 256 * launches_per_pixel_block >= 2 * NUM_CU;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagnostic build (-DMPC_STAMPS): in-kernel timestamps.  Thread 0 of every workgroup records the 100 MHz
+// constant-rate counter at up to 6 points (plus the shader-clock ticks of its K loop and its hardware id) into a
+// buffer of the kernel's own; with MPC_DUMP=<file> in the environment the launch synchronises and writes one line per
+// workgroup (tools/stamps_report.py digests it).  No stamp exists in a normal build.
+// ---------------------------------------------------------------------------------------------
+#if defined(MPC_STAMPS) && defined(__HIPCC__)
+#include <stdio.h>
+
+#include <vector>
+static __device__ unsigned long long *g_stamps;
+#define MPC_STAMP_DECL(wg_linear) unsigned long long *stamps_ = g_stamps + (size_t)(wg_linear) * 16; unsigned long long kclk_ = 0, seg_[5] = {0, 0, 0, 0, 0}, tprev_ = 0; (void)kclk_; (void)seg_; (void)tprev_;
+#define MPC_STAMP(i)                                                                                         \
+    if (threadIdx.x == 0) {                                                                                  \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                       \
+        stamps_[i] = t_;                                                                                     \
+    }
+#define MPC_STAMP_KBEGIN() kclk_ = tprev_ = __builtin_amdgcn_s_memtime();
+// shader-clock cycles of wave 0 between consecutive MPC_SEG marks, summed per mark index over the K loop
+#define MPC_SEG(i)                                                                                           \
+    {                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        seg_[i] += t_ - tprev_;                                                                              \
+        tprev_ = t_;                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+#define MPC_STAMP_KEND()                                                                                     \
+    if (threadIdx.x == 0) {                                                                                  \
+        stamps_[6] = __builtin_amdgcn_s_memtime() - kclk_;                                                   \
+        unsigned hw_;                                                                                        \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                    \
+        stamps_[7] = hw_;                                                                                    \
+        for (int i_ = 0; i_ < 5; ++i_) stamps_[8 + i_] = seg_[i_];                                           \
+    }
+struct StampHost {
+    unsigned long long *dbuf = nullptr;
+    size_t nwg = 0;
+    void before(size_t n) {
+        nwg = n;
+        if (!dbuf) (void)hipMalloc(&dbuf, sizeof(unsigned long long) * 16 * (1 << 17));
+        (void)hipMemset(dbuf, 0, sizeof(unsigned long long) * 16 * nwg);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbuf, sizeof(dbuf));
+    }
+    void after(hipStream_t stream, size_t blocks_per_phase, size_t min_wg) {
+        const char *path = getenv("MPC_DUMP");
+        if (!path || nwg < min_wg) return;
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(16 * nwg);
+        (void)hipMemcpy(h.data(), dbuf, sizeof(unsigned long long) * 16 * nwg, hipMemcpyDeviceToHost);
+        FILE *fp = fopen(path, "w");
+        if (!fp) return;
+        for (size_t i = 0; i < nwg; ++i) {
+            for (int k = 0; k < 8; ++k) fprintf(fp, "%llu ", h[16 * i + k]);
+            fprintf(fp, "%d", (int)(i / blocks_per_phase));
+            for (int k = 8; k < 13; ++k) fprintf(fp, " %llu", h[16 * i + k]);
+            fprintf(fp, "\n");
+        }
+        fclose(fp);
+    }
+};
+#else
+#define MPC_STAMP_DECL(wg_linear)
+#define MPC_STAMP(i)
+#define MPC_STAMP_KBEGIN()
+#define MPC_STAMP_KEND()
+#define MPC_SEG(i)
+#endif
+
 // Layer object behind the opaque mpc_conv handle.
 struct mpc_conv {
     mpc_conv_desc desc;

@@ -71,9 +71,12 @@ struct Body {
     static __device__ __forceinline__ void run(const Params &p, const Phase &ph, f4 *lds) {
         f4 *patch = lds;                                 // 2 x PATCH_F4
         f4 *wring = lds + 2 * PATCH_F4;                  // 3 x WCH_F4
+        f4 *par = wring + 3 * WCH_F4;                    // bias [COUT], beta [COUT] (beyond what the transposing store reuses)
 
         const int tid = threadIdx.x;
         const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+        MPC_STAMP_DECL(blockIdx.y * gridDim.x + blockIdx.x)
+        MPC_STAMP(0)
 
         const int tiles_x = (p.Wb + TILE_W - 1) / TILE_W, tiles_y = (p.Hb + TILE_H - 1) / TILE_H;
         const int64_t blk = xcd_block();
@@ -122,19 +125,29 @@ struct Body {
             }
         };
 
-        f32x16 acc[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
-
-        // prologue: weights of steps 0 and 1, patch of block 0
+        // prologue: weights of steps 0 and 1, patch of block 0; bias and beta go to LDS, where the epilogue finds them
+        // without a trip to L2
         dma_w(w_half(0, 0), 0);
         dma_w(w_half(1, 0), 1);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
+        if (tid < COUT / 4) par[tid] = ((const f4 *)p.bias)[tid];
+        if (EPI == EPI_GDN && tid >= 64 && tid < 64 + COUT / 4) par[COUT / 4 + tid - 64] = ((const f4 *)p.beta)[tid - 64];
         MPC_WAIT_VMCNT(0);
         __syncthreads();
+
+        // the accumulators start from the bias: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h
+        f32x16 acc[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4 bb = par[8 * f + 2 * g + h];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[f][4 * g + t] = bb[t];
+            }
+        MPC_STAMP(1)
+        MPC_STAMP_KBEGIN()
 
         // this lane's pixel in the patch (tap (0,0) is patch row + 1, column + 1), piece h of each k-step
         const int lane_slot = (2 * wave + (j >> 4) + 1) * ROW_F4 + ((j & 15) + 1) * PIX_F4 + h;
@@ -149,11 +162,15 @@ struct Body {
                              : more            ? w_half(TAP + 2 - NTAPS, cb + 1)
                              : (EPI == EPI_GDN) ? gsrc + (int64_t)(TAP + 2 - NTAPS) * WCH_F4
                                                 : wsrc;
-            dma_w(nsrc, slot >= 1 ? slot - 1 : 2);
             // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
             constexpr int first = TAP * ((PPW + (NTAPS - 2) - 1) / (NTAPS - 2));
+            auto issue = [&]() {
+                dma_w(nsrc, slot >= 1 ? slot - 1 : 2);
 #pragma unroll
-            for (int i = 0; i < pieces_in_step<NTAPS>(TAP); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
+                for (int i = 0; i < pieces_in_step<NTAPS>(TAP); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
+            };
+            issue();
+            MPC_SEG(0)
 
             const int2 d = p.tapv[ph.tap_off + TAP];     // uniform index: a scalar load from the kernel arguments
             const f4 *bp = patch + pbuf * PATCH_F4 + lane_slot + d.x * ROW_F4 + d.y * PIX_F4;
@@ -168,17 +185,14 @@ struct Body {
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
-            // order of the step: the operands of the first k-step, the second k-step's reads in front of the first's MFMAs
-#ifdef MPC_DP_GROUPS
-            __builtin_amdgcn_sched_group_barrier(0x100, NF + 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NF, 0);
-#endif
             // all but this step's transfers and the previous step's patch pieces have landed: the next step's weights
             // (issued one step ago, before that step's patch pieces) among them
+            MPC_SEG(1)
             MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
+            MPC_SEG(2)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            MPC_SEG(3)
             slot = slot == 2 ? 0 : slot + 1;
         };
 
@@ -200,45 +214,53 @@ struct Body {
             pbuf ^= 1;
         }
 
+        MPC_STAMP(2)
+        MPC_STAMP_KEND()
         // ---- epilogue: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h of pixel (by, bx) --------------------
         const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
-#pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 bb = *(const float4 *)(p.bias + 32 * f + 8 * g + 4 * h);
-                acc[f][4 * g + 0] += bb.x;
-                acc[f][4 * g + 1] += bb.y;
-                acc[f][4 * g + 2] += bb.z;
-                acc[f][4 * g + 3] += bb.w;
-            }
         if constexpr (EPI == EPI_GDN) {
             const bool inverse = p.act == MPC_ACT_IGDN;
             // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF more steps: half chunk hc holds gamma[:, 32 hc .. 32 hc + 31]
             // in the weight layout; the B operand is built from the lane's own accumulators, whose registers 8s..8s+7
             // of tile hc are the 8 k-values of k-step s (c = 32 hc + 16 s + 8(jj>>2) + 4h + (jj&3)).  y^2 is scaled by
             // 2^-8 and saturated before the conversion to fp16; the scale is undone on the fp32 sum.
-            f32x16 nrm[NF];
+            f32x16 nrm[NF];                               // starts from beta (in the scale of the sum: 2^-8)
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const f4 be = par[COUT / 4 + 8 * f + 2 * g + h];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) nrm[f][4 * g + t] = be[t] * SQ_SCALE;
+                }
+            auto square = [&](int hc, int s2) {
+                half8 bv;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    float y = acc[hc][8 * s2 + jj];
+                    bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                }
+                return bv;
+            };
+            half8 bv0 = square(0, 0), bv1 = square(0, 1);
 #pragma unroll
             for (int hc = 0; hc < NF; ++hc) {
                 dma_w(gsrc + (int64_t)(hc + 2 < NF ? hc + 2 : 0) * WCH_F4, slot >= 1 ? slot - 1 : 2);
                 const f4 *wl = wring + slot * WCH_F4 + h * COUT + j;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    half8 bv;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        float y = acc[hc][8 * s + jj];
-                        bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
-                    }
-#pragma unroll
-                    for (int fo = 0; fo < NF; ++fo)
-                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[(s * 2) * COUT + fo * 32]), bv, nrm[fo], 0, 0, 0);
+                // the next step's operands are squared and converted while this step's MFMAs run
+                half8 bn0 = bv0, bn1 = bv1;
+                if (hc + 1 < NF) {
+                    bn0 = square(hc + 1, 0);
+                    bn1 = square(hc + 1, 1);
                 }
+#pragma unroll
+                for (int fo = 0; fo < NF; ++fo)
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[fo * 32]), bv0, nrm[fo], 0, 0, 0);
+#pragma unroll
+                for (int fo = 0; fo < NF; ++fo)
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
+                bv0 = bn0;
+                bv1 = bn1;
                 MPC_WAIT_VMCNT(WPW);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -246,6 +268,7 @@ struct Body {
             }
             MPC_WAIT_VMCNT(0);                            // the surplus DMA pieces have landed before the LDS is reused
             __syncthreads();
+            MPC_STAMP(3)
             // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
             // all output channels in one round); v_rsq_f32 is far more accurate than the fp16 output
             TransStore ts;
@@ -254,19 +277,19 @@ struct Body {
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 be = *(const float4 *)(p.beta + 32 * f + 8 * g + 4 * h);
-                    const float bev[4] = {be.x, be.y, be.z, be.w};
                     half4 o;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float a = nrm[f][4 * g + t] * SQ_UNSCALE + bev[t];
+                        float a = nrm[f][4 * g + t] * SQ_UNSCALE;
                         float rs = __builtin_amdgcn_rsqf(a);
                         float y = acc[f][4 * g + t];
                         o[t] = sat_half(inverse ? y * (a * rs) : y * rs);
                     }
                     *(half4 *)ts.at(j, f * 64 + (8 * g + 4 * h) * 2) = o;
                 }
+            MPC_STAMP(4)
             ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
+            MPC_STAMP(5)
         } else {
             MPC_WAIT_VMCNT(0);                            // no DMA is left in flight when the workgroup ends
             if (!pvalid) return;
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void deconv5s2_patch_f16_kernel(const Params
 
 template <int NF, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase) {
-    size_t lds = ((size_t)2 * PATCH_F4 + 3 * (size_t)NF * 32 * 4) * sizeof(f4);
+    size_t lds = ((size_t)2 * PATCH_F4 + 3 * (size_t)NF * 32 * 4 + 2 * NF * 8) * sizeof(f4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
     auto kern = deconv5s2_patch_f16_kernel<NF, EPI>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
@@ -314,8 +337,15 @@ int launch(mpc_ctx *ctx, const Params &p, int nphase) {
     const int64_t tiles = (int64_t)p.B * mpc_cdiv(p.Hb, TILE_H) * mpc_cdiv(p.Wb, TILE_W);
     const int64_t bx = xcd_grid(tiles);
     MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many tiles");
+#ifdef MPC_STAMPS
+    static StampHost stamps;
+    stamps.before((size_t)bx * nphase);
+#endif
     kern<<<dim3((unsigned)bx, (unsigned)nphase, 1), dim3(NT), lds, ctx->stream>>>(p);
     MPC_CHECK_LAUNCH(ctx, "deconv5s2_patch_f16");
+#ifdef MPC_STAMPS
+    stamps.after(ctx->stream, (size_t)bx, 4000);
+#endif
     return MPC_OK;
 }
 

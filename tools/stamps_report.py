@@ -14,6 +14,10 @@ for ph, rs in sorted(by_phase.items()):
     n = len(rs)
     seg = [sum(r[i + 1] - r[i] for r in rs) / n / 100 for i in range(5)]
     clk = sum(r[6] / max(r[2] - r[1], 1) for r in rs) / n * 100 / 1000
+    if len(rs[0]) > 9:
+        steps = {0: 54, 1: 36, 2: 36, 3: 24}.get(ph, 1)
+        sg = [sum(r[9 + i] for r in rs) / n / steps for i in range(4)]
+        print(f"   per step (cycles of wave 0, {steps} steps): dma issue {sg[0]:.0f}, reads+mfma {sg[1]:.0f}, vmcnt wait {sg[2]:.0f}, barrier {sg[3]:.0f}")
     print(f"phase {ph}: n={n} prologue {seg[0]:.2f} K {seg[1]:.2f} gdn {seg[2]:.2f} math {seg[3]:.2f} flush {seg[4]:.2f} total {sum(seg):.2f} us; K-loop clock {clk:.2f} GHz")
 # per CU timeline: key = (xcd = index % 8, hw cu/sh/se bits)
 cus = collections.defaultdict(list)
