@@ -14,7 +14,7 @@
 // channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
 // streamed by LDS-DMA through a ring of three half chunks, two steps ahead; the next channel block's patch is brought
 // by LDS-DMA into the other patch buffer during the first steps of the current block.  No transfer passes through
-// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one counted s_waitcnt, one s_barrier.
+// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one s_waitcnt vmcnt(0), one s_barrier.
 //
 // LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
 // one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
@@ -185,10 +185,13 @@ struct Body {
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
-            // all but this step's transfers and the previous step's patch pieces have landed: the next step's weights
-            // (issued one step ago, before that step's patch pieces) among them
+            // Every transfer this wave has issued has landed before the barrier -- a full drain, not a counted wait
+            // that would leave this step's pieces in flight.  Counted waits (all but the youngest WPW + patch pieces)
+            // gave wrong values in a few tiles of the largest layer, a different few on every run (a determinism loop
+            // over 40 launches; the drain costs 2 %): with two workgroups per CU fetching the same weights, this
+            // kernel's LDS-DMA pieces did not complete in the order they were issued.
             MPC_SEG(1)
-            MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
+            MPC_WAIT_VMCNT(0);
             MPC_SEG(2)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -261,7 +264,7 @@ struct Body {
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
                 bv0 = bn0;
                 bv1 = bn1;
-                MPC_WAIT_VMCNT(WPW);
+                MPC_WAIT_VMCNT(0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;

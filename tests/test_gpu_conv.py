@@ -285,3 +285,31 @@ def test_split_precision_first_layer_rgb(dev, ops):
     exs = ((gots - ref).abs().max() / ref.abs().max()).item()
     print(f"first layer: rel err vs fp64  f32-MFMA {e32:.2e}   f16x3 {ex3:.2e}   f16x3 split-out {exs:.2e}")
     assert ex3 < 3e-6 and exs < 3e-6
+
+
+@pytest.mark.parametrize("which", ["deconv_f16", "conv_x3"])
+def test_big_layers_are_bit_identical_from_launch_to_launch(dev, ops, which):
+    """The LDS-DMA kernels at a size that fills the chip (two workgroups per CU, thousands of workgroups): 12 launches on
+    one input must give one result.  A transfer that is read before it has landed shows up here as a few tiles that
+    change from run to run (it does not show at small sizes, where a CU holds one workgroup)."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    c = 192
+    beta, gamma = (t.to(dev) for t in synth._gdn(g, c))
+    b = (torch.randn(c, generator=g) * 0.1).to(dev)
+    if which == "deconv_f16":
+        w = (torch.randn(c, c, 5, 5, generator=g) * 0.02).to(dev)
+        layer = ops.ConvLayer(_lib.MPC_DECONV, w, b, 5, 2, _lib.MPC_ACT_IGDN, beta, gamma, f16=True)
+        x = torch.randn(4, 128, 192, c, generator=g).half().to(dev)
+        run = lambda: layer(x)
+    else:
+        w = (torch.randn(c, c, 5, 5, generator=g) * 0.02).to(dev)
+        layer = ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2, _lib.MPC_ACT_GDN, beta, gamma, x3=True, in_bound=1.0)
+        xs = torch.randn(4, 256, 384, c // 8, 16, generator=g) * 40
+        xs[..., 8:] *= 1e-3
+        x = xs.half().to(dev)
+        run = lambda: layer(x, out_split=True)
+    first = run().clone()
+    differing = sum(int(not torch.equal(run(), first)) for _ in range(12))
+    print(f"{layer.kernel_name}: {differing} of 12 launches differ from the first")
+    assert differing == 0
