@@ -113,7 +113,7 @@ def parse(argv=None):
                     help="g_a arithmetic: exact f32 MFMA, or split-precision fp16 MFMA (fp32-grade, same symbols)")
     ap.add_argument("--synthesis-precision", default="fp16", choices=["fp32", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=16, help="images of the CPU baseline's sample at the larger thread count")
+    ap.add_argument("--cpu-images", type=int, default=40, help="images of the CPU baseline's sample at the larger thread count")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo ranks on the CPU with a stub step, to rehearse the launcher and the statistics path")
     args = ap.parse_args(argv)

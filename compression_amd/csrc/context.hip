@@ -29,7 +29,7 @@ void mpc_ctx_scratch_release(mpc_ctx *ctx) {
 
 extern "C" {
 
-const char *mpc_version(void) { return "libmpc 0.2 gfx950 (hand-written HIP: f32 / split-fp16 / fp16 MFMA transforms, prior competition, MRS1 rANS)"; }
+const char *mpc_version(void) { return "libmpc 0.3 gfx950 (hand-written HIP: f32 / split-fp16 / fp16 MFMA transforms with LDS-patch kernels, prior competition, MRS1 rANS)"; }
 
 int mpc_create(int device_id, void *stream, mpc_ctx **out) {
     if (!out) return MPC_EINVAL;
