@@ -65,7 +65,7 @@ PMC_META = os.path.join(REPO, "profiles", "r2_pmc_meta.json")
 
 def kernel_peak(name):
     """(peak TFLOP/s of the MFMA type the kernel issues, MFMA instructions issued per algorithmic product)."""
-    if name.startswith("conv_igemm_x3") or name.startswith("conv5s2_patch_x3"):
+    if name.startswith("conv_igemm_x3") or name.startswith("conv5s2_patch_x3") or name.startswith("conv1_rgb_patch_x3"):
         return PEAK_F16_MFMA_TFLOPS, 3        # a = hi + lo: three fp16 MFMAs per product
     if name.startswith("conv_igemm_f16") or name.startswith("deconv5s2_patch_f16"):
         return PEAK_F16_MFMA_TFLOPS, 1

@@ -86,8 +86,10 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
     };
 
     // ---- weights: chunk (tap, cb) of the packed image, brought by LDS-DMA into a ring of three chunks -----------
-    // Chunk c + 2 is issued during tap c and has to have landed by the end of tap c + 1: two taps of latency for the
-    // weights, and -- the vector-memory counter retires in issue order -- for the patch load issued beside them.
+    // Chunk c + 2 is issued at the top of tap c, and every wave drains its transfers (vmcnt(0)) before the tap's
+    // barrier.  A counted wait that left the youngest pieces in flight (the chunk would then have two taps to land)
+    // is 6 % faster and gave one wrong launch in 500 of the largest layer: LDS-DMA pieces cannot be relied on to be
+    // in LDS, in issue order, when the counter says so.
     const int ncb = p.Cs / 16;                            // 16-channel blocks
     const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group);
     const bool gdn_mix16 = (EPI == EPI_GDN) && p.y2_scale > 0.0f;
@@ -120,8 +122,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
     const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * ROW_F4 + (2 * h) * X2 + (j & 15);
     int slot = 0;                                         // ring slot of the current chunk; the chunk after next goes to slot + 2
     // One tap of the current 16-channel block, expanded 25 times with a literal tap number: the staging registers are
-    // addressed by constants and the number of vector-memory operations that may stay in flight at the end of the tap
-    // (this tap's DMA pieces, its patch load, the previous tap's patch load) is a constant as well.
+    // addressed by constants.
 #define MPC_PATCH_TAP(TAP)                                                                                             \
     {                                                                                                                  \
         constexpr int tap = (TAP), dyp = tap / 5, dxp = tap % 5;                                                      \
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        MPC_WAIT_VMCNT(WPW + (tap < NS ? 1 : 0) + ((tap >= 1 && tap - 1 < NS) ? 1 : 0));                               \
+        MPC_WAIT_VMCNT(0);                                                                                             \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         slot = slot == 2 ? 0 : slot + 1;                                                                               \
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
                 }
-                MPC_WAIT_VMCNT(WPW);
+                MPC_WAIT_VMCNT(0);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;
@@ -234,6 +235,206 @@ int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
     return MPC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// First layer (3 -> COUT, 5x5 stride 2, fused GDN) in the same style.  Its K axis is short (k = tap*4 + c over the
+// image padded to 4 channels: 25 taps -> 8 k-steps, then 2 NF k-steps of the GDN mix), so a workgroup lives for only
+// 8 + 2 NF steps and what matters is that nothing in them waits: the whole 35 x 19 image patch of the 16 x 8 output
+// tile is split into fp16 hi/lo ONCE, when it is staged ([hi x4 | lo x4] = one 16-byte slot per pixel, column
+// parities apart so that the 16 lanes of a tile row read consecutive slots), the weights and gamma stream through
+// the LDS-DMA ring, and two workgroups share a CU so that one's prologue and 768-byte-per-pixel stores overlap the
+// other's MFMAs.  A lane's 8 k-values of a k-step are two whole pixels: taps 4S + 2h and 4S + 2h + 1.
+constexpr int RGB_X2 = 18;                          // slots per column parity
+constexpr int RGB_ROW = 2 * RGB_X2;                 // 36 slots per patch row
+constexpr int RGB_TR = 8, RGB_PR = 2 * RGB_TR + 3;  // 8 tile rows, 19 patch rows
+constexpr int RGB_PATCH = 704;                      // 19 x 36 = 684 slots, rounded up
+
+__host__ __device__ constexpr int rgb_tap_slot(int tap) {       // slot offset of a tap inside the patch (taps past 24: weights are zero)
+    const int t = tap > 24 ? 24 : tap;
+    return (t / 5) * RGB_ROW + ((t % 5) & 1) * RGB_X2 + ((t % 5) >> 1);
+}
+
+template <int NF>
+__global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params p) {
+    constexpr int NW = 4, NT = 64 * NW, COUT = NF * 32;
+    constexpr int WCH_F4 = COUT * 4;                     // slots of a half chunk (one k-step): [h][hi|lo][cout]
+    constexpr int WPW = WCH_F4 / 64 / NW;
+    constexpr int KSTEPS = 8;                            // 25 taps x 4 channels = 100 -> 128 = 8 x 16
+    static_assert(WPW * NW * 64 == WCH_F4, "a half chunk must split evenly into 1 KB pieces per wave");
+    extern __shared__ f4 lds[];
+    f4 *patch = lds;
+    f4 *wring = lds + RGB_PATCH;                         // 3 x WCH_F4
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    MPC_STAMP_DECL(blockIdx.x)
+    MPC_STAMP(0)
+    const int tiles_x = (p.Wo + TILE_W - 1) / TILE_W, tiles_y = (p.Ho + RGB_TR - 1) / RGB_TR;
+    const int64_t blk = xcd_block();
+    if (blk >= (int64_t)p.B * tiles_y * tiles_x) return;     // padding block of the rounded-up grid
+    const int b = (int)(blk / (tiles_y * tiles_x));
+    const int trem = (int)(blk - (int64_t)b * tiles_y * tiles_x);
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int oy = ty * RGB_TR + 2 * wave + (j >> 4), ox = tx * TILE_W + (j & 15);
+    const bool pvalid = oy < p.Ho && ox < p.Wo;
+
+    const f4 *wsrc = (const f4 *)p.wpk;
+    const f4 *gsrc = (const f4 *)p.gamma_x3;
+    auto dma_chunk = [&](const f4 *chunk_src, int slot) {
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) {
+            const int piece = wave * WPW + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
+                                             (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
+        }
+    };
+    // the chunk stream: 8 half chunks of weights, then the 2 NF half chunks of gamma, then (unused) the first again
+    auto stream = [&](int c) -> const f4 * {
+        return c < KSTEPS ? wsrc + (int64_t)c * WCH_F4 : (c < KSTEPS + 2 * NF ? gsrc + (int64_t)(c - KSTEPS) * WCH_F4 : wsrc);
+    };
+
+    dma_chunk(stream(0), 0);
+    dma_chunk(stream(1), 1);
+    // the image patch: fp32 pixel (4 channels) -> [hi x4 | lo x4] of value * 2^8
+    {
+        const f4 *img = (const f4 *)p.in + (int64_t)b * p.Hi * p.Wi;
+        const int iy0 = 2 * ty * RGB_TR - 2, ix0 = 2 * tx * TILE_W - 2;
+#pragma unroll
+        for (int i = 0; i < (RGB_PR * RGB_ROW + NT - 1) / NT; ++i) {
+            const int s = tid + i * NT;
+            const int r = s / RGB_ROW, rem = s - r * RGB_ROW;
+            const int par = rem / RGB_X2, x2 = rem - par * RGB_X2;
+            const int px = 2 * x2 + par, iy = iy0 + r, ix = ix0 + px;
+            const bool ok = s < RGB_PR * RGB_ROW && px < PATCH_COLS && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = img[(int64_t)iy * p.Wi + ix];
+            half4 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sv = v[c] * X3_ACT_SCALE;
+                const _Float16 hh = (_Float16)sv;
+                hi[c] = hh;
+                lo[c] = (_Float16)(sv - (float)hh);
+            }
+            struct { half4 a, b; } two = {hi, lo};
+            if (s < RGB_PR * RGB_ROW) patch[s] = __builtin_bit_cast(f4, two);
+        }
+    }
+    MPC_WAIT_VMCNT(0);
+    __syncthreads();
+    MPC_STAMP(1)
+    MPC_STAMP_KBEGIN()
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
+
+    const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * RGB_ROW + (j & 15);
+    int slot = 0;
+#define MPC_RGB_STEP(S)                                                                                                \
+    {                                                                                                                  \
+        dma_chunk(stream((S) + 2), slot >= 1 ? slot - 1 : 2);                                                          \
+        const f4 s0 = bbase[h ? rgb_tap_slot(4 * (S) + 2) : rgb_tap_slot(4 * (S))];                                     \
+        const f4 s1 = bbase[h ? rgb_tap_slot(4 * (S) + 3) : rgb_tap_slot(4 * (S) + 1)];                                 \
+        const half8 bh = as_half8(f4{s0[0], s0[1], s1[0], s1[1]}), bl = as_half8(f4{s0[2], s0[3], s1[2], s1[3]});       \
+        const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;                                                     \
+        _Pragma("unroll") for (int f = 0; f < NF; ++f) {                                                               \
+            const half8 ah = as_half8(wl[f * 32]);                                                                     \
+            const half8 al = as_half8(wl[COUT + f * 32]);                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[f], 0, 0, 0);                                  \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
+        }                                                                                                              \
+        MPC_WAIT_VMCNT(0);                                                                                             \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+        slot = slot == 2 ? 0 : slot + 1;                                                                               \
+    }
+    MPC_RGB_STEP(0) MPC_RGB_STEP(1) MPC_RGB_STEP(2) MPC_RGB_STEP(3)
+    MPC_RGB_STEP(4) MPC_RGB_STEP(5) MPC_RGB_STEP(6) MPC_RGB_STEP(7)
+#undef MPC_RGB_STEP
+
+    MPC_STAMP(2)
+    MPC_STAMP_KEND()
+    // ---- epilogue: scales, bias, the GDN mix as 2 NF more steps, normalisation and full-line stores ----------------
+    x3_unscale_bias<NF>(p, acc, 0, h);
+    const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
+    f32x16 nrm[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+    // the B operand of step (kc, s): the lane's accumulators 8s..8s+7 of tile kc, squared, scaled and split; built one
+    // step ahead, so that the conversions run beside the previous step's MFMAs instead of in front of this step's
+    auto square = [&](int kc, int s2, half8 &bh, half8 &bl) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            float y = acc[kc][8 * s2 + jj];
+            float q = fminf(y * y * p.y2_scale, 65504.0f);
+            _Float16 hh = (_Float16)q;
+            bh[jj] = hh;
+            bl[jj] = (_Float16)(q - (float)hh);
+        }
+    };
+    half8 bh, bl;
+    square(0, 0, bh, bl);
+#pragma unroll
+    for (int hc = 0; hc < 2 * NF; ++hc) {
+        dma_chunk(stream(KSTEPS + hc + 2), slot >= 1 ? slot - 1 : 2);
+        const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;
+        half8 nh = bh, nl = bl;
+        if (hc + 1 < 2 * NF) square((hc + 1) >> 1, (hc + 1) & 1, nh, nl);
+#pragma unroll
+        for (int fo = 0; fo < NF; ++fo) {
+            const half8 ah = as_half8(wl[fo * 32]);
+            const half8 al = as_half8(wl[COUT + fo * 32]);
+            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm[fo], 0, 0, 0);
+            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
+            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
+        }
+        bh = nh;
+        bl = nl;
+        MPC_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    MPC_WAIT_VMCNT(0);                                    // the surplus DMA pieces have landed before the LDS is reused
+    __syncthreads();
+    MPC_STAMP(3)
+    MPC_STAMP(4)
+    x3_gdn_store<NF>(p, acc, nrm, (float4 *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
+    MPC_STAMP(5)
+}
+
+template <int NF>
+int launch_rgb(mpc_ctx *ctx, const Params &p) {
+    size_t lds = ((size_t)RGB_PATCH + 3 * (size_t)NF * 32 * 4) * sizeof(float4);
+    if (lds < (size_t)4 * TS_WAVE_BYTES) lds = (size_t)4 * TS_WAVE_BYTES;
+    auto kern = conv1_rgb_patch_x3_kernel<NF>;
+    static bool attr_set[MPC_MAX_DEVICES] = {};
+    bool &attr_done = attr_set[ctx->device];
+    if (!attr_done) {
+        MPC_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int64_t tiles = (int64_t)p.B * mpc_cdiv(p.Ho, RGB_TR) * mpc_cdiv(p.Wo, TILE_W);
+    const int64_t bx = xcd_grid(tiles);
+    MPC_REQUIRE(ctx, bx < (1ll << 31), "conv: too many tiles");
+#ifdef MPC_STAMPS
+    static StampHost stamps;
+    stamps.before((size_t)bx);
+#endif
+    kern<<<dim3((unsigned)bx, 1, 1), dim3(256), lds, ctx->stream>>>(p);
+    MPC_CHECK_LAUNCH(ctx, "conv1_rgb_patch_x3");
+#ifdef MPC_STAMPS
+    stamps.after(ctx->stream, (size_t)bx, 4000);
+#endif
+    return MPC_OK;
+}
+
 }  // namespace
 
 // True when the layer / call can run on the patch kernel.
@@ -258,4 +459,18 @@ int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     if (!gdn && c->nf == 6) return launch_tr<6, EPI_PLAIN, 8>(ctx, p, ng);
     if (!gdn && c->nf == 4) return launch_tr<4, EPI_PLAIN, 8>(ctx, p, ng);
     MPC_FAIL(ctx, MPC_EINVAL, "conv_forward (f16x3 patch kernel): unsupported layer shape (cout/32 = %d)", c->nf);
+}
+
+// The 3-channel first layer with a fused GDN mix on the fp16 pipe (5x5 stride 2, one output-channel group).
+bool mpc_conv_rgb_patch_x3_supported(const Params &p, const mpc_conv *c) {
+    const mpc_conv_desc &d = c->desc;
+    if (!c->x3 || !c->cin4 || d.kind != MPC_CONV || d.ksize != 5 || d.stride != 2 || d.pad != 2) return false;
+    if (d.act != MPC_ACT_GDN || !(p.gamma_x3 && p.y2_scale > 0.0f)) return false;
+    if ((c->nf != 4 && c->nf != 6) || c->groups != 1 || c->nphase != 1 || c->ph[0].ntaps != 25 || c->ph[0].nchunks != 4) return false;
+    return true;
+}
+
+int mpc_conv_launch_rgb_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
+    if (c->nf == 6) return launch_rgb<6>(ctx, p);
+    return launch_rgb<4>(ctx, p);
 }

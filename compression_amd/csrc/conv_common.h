@@ -261,3 +261,5 @@ int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // split-fp16 5x5 stride-2 layers with the input patch staged in LDS (conv5s2_patch_x3.hip)
 bool mpc_conv_patch_x3_supported(const Params &p, const mpc_conv *c);
 int mpc_conv_launch_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
+bool mpc_conv_rgb_patch_x3_supported(const Params &p, const mpc_conv *c);
+int mpc_conv_launch_rgb_patch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c);

@@ -323,6 +323,10 @@ int mpc_conv_launch_x3(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
         static const bool off = [] { const char *e = getenv("MPC_X3_PATCH"); return e && atoi(e) == 0; }();
         if (!off) return mpc_conv_launch_patch_x3(ctx, p, c);
     }
+    if (mpc_conv_rgb_patch_x3_supported(p, c)) {
+        static const bool off = [] { const char *e = getenv("MPC_X3_RGB_PATCH"); return e && atoi(e) == 0; }();   // development switch
+        if (!off) return mpc_conv_launch_rgb_patch_x3(ctx, p, c);
+    }
     const bool gdn = c->desc.act == MPC_ACT_GDN || c->desc.act == MPC_ACT_IGDN;
     const int np = c->nphase, ng = c->groups;
     if (c->cin4) {

@@ -34,6 +34,10 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifndef MPC_DMA_AUX
+#define MPC_DMA_AUX 0
+#endif
+
 namespace {
 
 constexpr float SQ_SCALE = 0.00390625f;      // 2^-8
@@ -105,7 +109,7 @@ struct Body {
             const _Float16 *src = soff[i] >= 0 ? in_b + soff[i] + cb * 32 : zeros;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(patch + buf * PATCH_F4 + (wave * PPW + i) * 64),
-                                             16, 0, 0);
+                                             16, 0, MPC_DMA_AUX);
         };
 
         // ---- weights: half chunk (tap, cb) of the packed image, then gamma's half chunks, by LDS-DMA ------------
@@ -121,7 +125,7 @@ struct Body {
             for (int q = 0; q < WPW; ++q) {
                 const int piece = wave * WPW + q;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
-                                                 (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, MPC_DMA_AUX);
             }
         };
 
@@ -191,7 +195,11 @@ struct Body {
             // over 40 launches; the drain costs 2 %): with two workgroups per CU fetching the same weights, this
             // kernel's LDS-DMA pieces did not complete in the order they were issued.
             MPC_SEG(1)
+#ifdef MPC_DP_COUNTED
+            MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
+#else
             MPC_WAIT_VMCNT(0);
+#endif
             MPC_SEG(2)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

@@ -562,6 +562,11 @@ class ConvLayer:
             and (not gdn or in_bound > 0.0)
         if self._patch:
             self._name_fmt = "conv5s2_patch_x3_kernel<%d, %d, 8>" % (nf, epi)
+        # the 3-channel first layer with a fused GDN has a patch kernel of its own
+        if x3 and cin <= 4 and kind == _lib.MPC_CONV and ksize == 5 and stride == 2 and act == _lib.MPC_ACT_GDN and in_bound > 0.0 \
+                and nf in (4, 6) and tiles == nf:
+            self._patch = True
+            self._name_fmt = "conv1_rgb_patch_x3_kernel<%d>" % nf
         # fp16 5x5 stride-2 transposed convolutions run on their own LDS-patch kernel (the library's dispatch conditions)
         self._dpatch = f16 and kind == _lib.MPC_DECONV and ksize == 5 and stride == 2 and cin % 64 == 0 and nf in (4, 6) \
             and not self.small_cout and cout <= 192

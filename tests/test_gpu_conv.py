@@ -287,7 +287,7 @@ def test_split_precision_first_layer_rgb(dev, ops):
     assert ex3 < 3e-6 and exs < 3e-6
 
 
-@pytest.mark.parametrize("which", ["deconv_f16", "conv_x3"])
+@pytest.mark.parametrize("which", ["deconv_f16", "conv_x3", "conv1_x3"])
 def test_big_layers_are_bit_identical_from_launch_to_launch(dev, ops, which):
     """The LDS-DMA kernels at a size that fills the chip (two workgroups per CU, thousands of workgroups): 12 launches on
     one input must give one result.  A transfer that is read before it has landed shows up here as a few tiles that
@@ -302,6 +302,12 @@ def test_big_layers_are_bit_identical_from_launch_to_launch(dev, ops, which):
         layer = ops.ConvLayer(_lib.MPC_DECONV, w, b, 5, 2, _lib.MPC_ACT_IGDN, beta, gamma, f16=True)
         x = torch.randn(4, 128, 192, c, generator=g).half().to(dev)
         run = lambda: layer(x)
+    elif which == "conv1_x3":
+        w = (torch.randn(c, 3, 5, 5, generator=g) * 0.1).to(dev)
+        layer = ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2, _lib.MPC_ACT_GDN, beta, gamma, x3=True, in_bound=1.0)
+        x = torch.rand(4, 512, 768, 4, generator=g).to(dev)
+        x[..., 3] = 0
+        run = lambda: layer(x, out_split=True)
     else:
         w = (torch.randn(c, c, 5, 5, generator=g) * 0.02).to(dev)
         layer = ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2, _lib.MPC_ACT_GDN, beta, gamma, x3=True, in_bound=1.0)

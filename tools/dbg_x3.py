@@ -11,7 +11,8 @@ w = (torch.randn(cout, cin, 5, 5, generator=g) * 0.02).to(dev)
 b = (torch.randn(cout, generator=g) * 0.1).to(dev)
 beta, gamma = (t.to(dev) for t in synth._gdn(g, cout))
 layer = ops.ConvLayer(_lib.MPC_CONV, w, b, 5, 2, _lib.MPC_ACT_GDN, beta, gamma, x3=True, in_bound=1.0)
-B, H, W = int(sys.argv[1]), 256, 384
+B = int(sys.argv[1])
+H, W = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (256, 384)
 x = (torch.randn(B, H, W, cin // 8, 16, device=dev) * 40).half()
 x[..., 8:] *= 1e-3
 ref = layer(x, out_split=True).clone()
