@@ -85,11 +85,17 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             if (tid + i * NT < PATCH_F4) patch[tid + i * NT] = soff[i] >= 0 ? stage[i] : f4{0.f, 0.f, 0.f, 0.f};
     };
 
-    // ---- weights: chunk (tap, cb) of the packed image, brought by LDS-DMA into a ring of three chunks -----------
-    // Chunk c + 2 is issued at the top of tap c, and every wave drains its transfers (vmcnt(0)) before the tap's
-    // barrier.  A counted wait that left the youngest pieces in flight (the chunk would then have two taps to land)
-    // is 6 % faster and gave one wrong launch in 500 of the largest layer: LDS-DMA pieces cannot be relied on to be
-    // in LDS, in issue order, when the counter says so.
+    // ---- weights: chunk (tap, cb) of the packed image, through a ring of three chunks in LDS ----------------------
+    // In the K loop a chunk travels global -> registers -> LDS: chunk c + 2 is loaded at the top of tap c and written
+    // to the ring at the end of tap c + 1, so it has two taps to arrive and the only waits are the compiler's counted
+    // ones on its registers.  LDS-DMA is not used there: its pieces cannot be relied on to be in LDS, in issue order,
+    // when a counted s_waitcnt says so (a counted wait gave one wrong launch in 500 of the largest layer), and the
+    // vmcnt(0) that is safe also waits for the patch loads of the next block, which are meant to stay in flight for
+    // many taps (that wait cost 6 % of the layer).  The GDN steps have no other load in flight and keep LDS-DMA with
+    // a vmcnt(0) per step.
+#ifndef MPC_X3_STAGED_W
+#define MPC_X3_STAGED_W 1
+#endif
     const int ncb = p.Cs / 16;                            // 16-channel blocks
     const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group);
     const bool gdn_mix16 = (EPI == EPI_GDN) && p.y2_scale > 0.0f;
@@ -102,6 +108,8 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
     };
+    const int wofs = wave * WPW * 64 + lane;              // this thread's first slot of a chunk; the others 64 apart
+    f4 wo[WPW];                                           // the chunk after the current one, on its way to the ring
 
     f32x16 acc[NF];
 #pragma unroll
@@ -110,12 +118,21 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
 
     // prologue: weights of (tap 0, block 0) and (tap 1, block 0), patch of block 0
+#if MPC_X3_STAGED_W
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) wring[wofs + q * 64] = wsrc[wofs + q * 64];
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) wo[q] = wsrc[(int64_t)ncb * WCH_F4 + wofs + q * 64];
+#else
     dma_chunk(wsrc, 0);
     dma_chunk(wsrc + (int64_t)ncb * WCH_F4, 1);
+#endif
 #pragma unroll
     for (int i = 0; i < NS; ++i) load_slot(i, 0);
     write_patch();
+#if !MPC_X3_STAGED_W
     MPC_WAIT_VMCNT(0);
+#endif
     __syncthreads();
 
     // this lane's pixel in the patch: row 2*(row in tile), piece 2h (hi) / 2h+1 (lo), column slot (j & 15)
@@ -131,8 +148,9 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                          : more      ? wsrc + ((int64_t)(tap - 23) * ncb + cb + 1) * WCH_F4                            \
                          : gdn_mix16 ? gsrc + (int64_t)(tap - 23) * WCH_F4                                             \
                                      : wsrc;                                                                           \
-        dma_chunk(nsrc, slot >= 1 ? slot - 1 : 2);                                                                     \
+        MPC_X3_W_TOP(nsrc)                                                                                             \
         if constexpr (tap < NS) load_slot(tap, more ? cb + 1 : cb); /* (the last block re-reads its own: unused) */   \
+        __builtin_amdgcn_sched_barrier(0);                  /* the loads stay at the top of the tap */                 \
         const f4 *bp = bbase + dyp * ROW_F4 + (dxp & 1) * (4 * X2) + (dxp >> 1);                                       \
         const half8 bh = as_half8(bp[0]), bl = as_half8(bp[X2]);                                                       \
         const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;                                                     \
@@ -143,11 +161,24 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        MPC_WAIT_VMCNT(0);                                                                                             \
+        MPC_X3_W_END()                                                                                                 \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         slot = slot == 2 ? 0 : slot + 1;                                                                               \
     }
+#if MPC_X3_STAGED_W
+#define MPC_X3_W_TOP(SRC)                                                                                              \
+        f4 wn[WPW];                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < WPW; ++q) wn[q] = (SRC)[wofs + q * 64];
+#define MPC_X3_W_END()                                                                                                 \
+        {                                                                                                              \
+            f4 *wdst = wring + (slot == 2 ? 0 : slot + 1) * WCH_F4 + wofs;                                             \
+            _Pragma("unroll") for (int q = 0; q < WPW; ++q) { wdst[q * 64] = wo[q]; wo[q] = wn[q]; }                   \
+        }
+#else
+#define MPC_X3_W_TOP(SRC) dma_chunk(SRC, slot >= 1 ? slot - 1 : 2);
+#define MPC_X3_W_END() MPC_WAIT_VMCNT(0);
+#endif
     for (int cb = 0; cb < ncb; ++cb) {
         const bool more = cb + 1 < ncb;
         MPC_PATCH_TAP(0) MPC_PATCH_TAP(1) MPC_PATCH_TAP(2) MPC_PATCH_TAP(3) MPC_PATCH_TAP(4)
@@ -162,6 +193,14 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
         }
     }
 #undef MPC_PATCH_TAP
+#undef MPC_X3_W_TOP
+#undef MPC_X3_W_END
+#if MPC_X3_STAGED_W
+    if (gdn_mix16) {                                      // the second half chunk of gamma, loaded at the last tap
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) wring[(slot == 2 ? 0 : slot + 1) * WCH_F4 + wofs + q * 64] = wo[q];
+    }
+#endif
 
     // ---- epilogue -------------------------------------------------------------------------------------------
     x3_unscale_bias<NF>(p, acc, cg, h);
