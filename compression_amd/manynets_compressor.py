@@ -145,20 +145,30 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         x = input_image.contiguous()
         B, _, H, W = x.shape
         npix = B * H * W
+        # Enqueue order: g_a -> competition -> (copy of the index map and the clamped count to the host) -> g_s and
+        # the loss.  The host then waits for the copy only, and does its part (which priors were used, the side
+        # string's candidates: the LZMA call alone is ~1 ms) while g_s runs.
         while True:
             yhat, sym4, nclamp = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1,
                                                               keep_rounded=True)
-            if int(nclamp.item()) == 0:
+            _, h, w, M = yhat.shape
+            sym = sym4.view(-1, M)
+            idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
+            n_loc = idx.numel()
+            host = self._meta_host(n_loc + 1)
+            host[:n_loc].copy_(idx.view(-1), non_blocking=True)
+            host[n_loc:].copy_(nclamp.view(-1)[:1], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
+            recon = self.Decoder.forward_nhwc(yhat)
+            xhat, visual_loss = self._visual_loss(recon, x)
+            copied.synchronize()                         # g_a and the competition have finished; g_s is still running
+            if int(host[n_loc]) == 0:
                 break
-            self._widen_tables()
-        _, h, w, M = yhat.shape
-        recon = self.Decoder.forward_nhwc(yhat)
-        xhat, visual_loss = self._visual_loss(recon, x)
-        sym = sym4.view(-1, M)
-        idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
+            self._widen_tables()                         # like the reference (manynets_compressor.py:212-227), then again
         dist_select = idx.view(B, h, w)
         self.last_dist_select = dist_select          # the prior index map of the last forward (int32 [B,h,w], on the GPU)
-        idx_cpu = dist_select.cpu()
+        idx_cpu = host[:n_loc].clone().view(B, h, w)
         used = np.unique(idx_cpu.numpy())
         self.dists_last_use[used] = 0
         self.dists_last_use[np.setdiff1d(np.arange(self.num_distributions), used, assume_unique=True)] += 1

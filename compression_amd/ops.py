@@ -20,8 +20,9 @@ class Profiler:
     """Optional per-call HIP-event timing of libmpc launches (events are recorded on torch's current
     stream, which is the stream the kernels are enqueued on).  Used by bench.py for the roofline numbers."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (name, start_event, end_event, meta)
+        self.only = only           # None: every launch; else the set of names to time (the others get no events)
 
     def summary(self):
         """-> {name: {"calls", "ms", "flops", "bytes"}} (synchronises)."""
@@ -44,13 +45,14 @@ class _timed:
         self.name, self.meta = name, meta
 
     def __enter__(self):
-        if PROFILER is not None:
+        self.on = PROFILER is not None and (PROFILER.only is None or self.name in PROFILER.only)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *exc):
-        if PROFILER is not None and exc[0] is None:
+        if self.on and PROFILER is not None and exc[0] is None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             PROFILER.records.append((self.name, self.e0, e1, self.meta))
