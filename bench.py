@@ -117,6 +117,8 @@ def parse(argv=None):
     ap.add_argument("--analysis-precision", default="f16x3", choices=["fp32", "f16x3"],
                     help="g_a arithmetic: exact f32 MFMA, or split-precision fp16 MFMA (fp32-grade, same symbols)")
     ap.add_argument("--synthesis-precision", default="fp16", choices=["fp32", "fp16"])
+    ap.add_argument("--serial", action="store_true",
+                    help="codec workloads: one batch after the other on one stream (default: two batches in flight on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=40, help="images of the CPU baseline's sample at the larger thread count")
     ap.add_argument("--dry-run", action="store_true",
@@ -367,7 +369,7 @@ def run_rank(args):
     acc = StatsAccumulator(device=dev)
     state = {"seconds": 0.0}
 
-    def codec_step():
+    def serial_codec_step():
         streams, idx, h, w = model.encode_batch(x)
         recon = model.decode_batch(streams, idx, h, w)
         xhat, sse = ops.clamp_sse_per_image(recon, target)
@@ -386,7 +388,40 @@ def run_rank(args):
         acc.all_reduce()
         return xhat
 
-    step = codec_step if args.mode == "codec" else forward_step
+    # Throughput mode (default for the codec workloads): two batches in flight on two streams, see
+    # compression_amd/pipeline.py.  Each batch's statistics are formed behind its g_s on its own stream.
+    accs = {}
+
+    def after_synthesis(recon, strings, tag):
+        xhat, sse = ops.clamp_sse_per_image(recon, target)
+        nbytes = float(sum(len(s) for s in strings))
+        a = accs.setdefault(torch.cuda.current_stream().cuda_stream, StatsAccumulator(device=dev))
+        a.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
+        a.all_reduce()
+        state["acc"] = a
+        return xhat
+
+    pipe = None
+    if args.mode == "codec" and not args.serial:
+        from compression_amd.pipeline import CodecPipeline
+        pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis)
+
+    def pipelined_codec_step():
+        r = pipe.submit(x)
+        return None if r is None else r[2]
+
+    def drain():
+        """-> x_hat of the batch still in flight, if any (the pipeline is empty afterwards)."""
+        if pipe is None:
+            return None
+        r = pipe.flush()
+        pipe.synchronize()
+        return None if r is None else r[2]
+
+    def keep_last(new, old):
+        return old if new is None else new
+
+    step = forward_step if args.mode != "codec" else (serial_codec_step if args.serial else pipelined_codec_step)
 
     def barrier():
         if dist is not None:
@@ -403,9 +438,10 @@ def run_rank(args):
     wprof = ops.PROFILER = ops.Profiler()
     for _ in range(max(args.warmup, 1)):
         t = time.perf_counter()
-        xhat = step()                                       # (kept, as in the timed loop: the allocator reaches its steady state here)
+        xhat = keep_last(step(), xhat)                      # (kept, as in the timed loop: the allocator reaches its steady state here)
         torch.cuda.synchronize()
         state["seconds"] = time.perf_counter() - t
+    xhat = keep_last(drain(), xhat)                                  # the timed region starts with nothing in flight
     ops.PROFILER = None
     wk = wprof.summary()
     dom = max(conv_names(wk), key=lambda n: wk[n]["ms"])
@@ -414,7 +450,8 @@ def run_rank(args):
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        xhat = step()
+        xhat = keep_last(step(), xhat)
+    xhat = keep_last(drain(), xhat)                                  # ... and ends with all of its K batches decoded
     barrier()
     dt = time.perf_counter() - t0
     device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the timed region
@@ -423,7 +460,8 @@ def run_rank(args):
     # the other kernels' averages: the same steps once more, outside the timed region, every launch between events
     aprof = ops.PROFILER = ops.Profiler()
     for _ in range(args.steps):
-        xhat = step()
+        xhat = keep_last(step(), xhat)
+    xhat = keep_last(drain(), xhat)
     ops.PROFILER = None
     kern = aprof.summary()
     kern[dom] = timed_dom
@@ -441,7 +479,8 @@ def run_rank(args):
         ms = None                                           # image too small for the 5 scales
     _, sse = ops.clamp_sse_per_image(xhat, target)
     rep = StatsAccumulator(device=dev)
-    last = acc.result()
+    torch.cuda.synchronize()
+    last = state.get("acc", acc).result()                   # (pipelined: the accumulator of the last batch's stream)
     rep.add_batch_device(sse, 3 * H * W, bits=last["bits"] / world, pixels=B * H * W, nbytes=last["bytes"] / world,
                          seconds=state["seconds"], side_bits=last["side_bits"] / world, msssim=ms, reset=True)
     stats = rep.all_reduce().result()
@@ -487,7 +526,8 @@ def run_rank(args):
         "config": {"workload": f"config {args.config}: {CONFIGS[args.config]['what']} per GPU, {args.arch} N=192 M=256 K=64, "
                                f"random-init weights with spread priors, {args.data} input",
                    "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
-                   "parallelism": f"image-sharded x{world}, statistics all-reduce only"},
+                   "parallelism": f"image-sharded x{world}, statistics all-reduce only",
+                   "batches_in_flight": 2 if pipe is not None else 1},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,

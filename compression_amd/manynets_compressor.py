@@ -268,20 +268,23 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         host = stage.numpy()
         return [host[i, :nb[i]].tobytes() for i in range(n_images)], (n_streams, lps)
 
-    def _staging(self, nbytes):
-        """Page-locked host buffer of at least nbytes (uint8), reused between calls."""
-        buf = getattr(self, "_stage_buf", None)
+    def _staging(self, nbytes, purpose="bytes"):
+        """Page-locked host buffer of at least nbytes (uint8), reused between calls.  One buffer per purpose and per HIP
+        stream: calls that are in flight on different streams (CodecPipeline) never share one."""
+        bufs = self.__dict__.setdefault("_stage_bufs", {})
+        key = (purpose, torch.cuda.current_stream().cuda_stream)
+        buf = bufs.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            self._stage_buf = buf
+            buf = bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
         return buf
 
-    def _meta_host(self, n):
-        """Page-locked int32 host buffer for the one small readback of a call."""
-        buf = getattr(self, "_meta_buf", None)
+    def _meta_host(self, n, purpose="meta"):
+        """Page-locked int32 host buffer for the one small readback of a call (per purpose and stream, as above)."""
+        bufs = self.__dict__.setdefault("_meta_bufs", {})
+        key = (purpose, torch.cuda.current_stream().cuda_stream)
+        buf = bufs.get(key)
         if buf is None or buf.numel() < n:
-            buf = torch.empty(max(n, 256), dtype=torch.int32, pin_memory=True)
-            self._meta_buf = buf
+            buf = bufs[key] = torch.empty(max(n, 256), dtype=torch.int32, pin_memory=True)
         return buf[:n]
 
     def encode_batch(self, input_image, entropy_coding=True):
@@ -289,8 +292,19 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
 
         The whole chain -- g_a with quantisation and symbolisation in the last layer's epilogue, prior competition, the
         coder with its stream geometry chosen on the device from the competition's bit estimate -- is enqueued without
-        the host reading anything back.  One small readback follows (sizes, coder status, clamped-symbol count), then
-        the copy of the used part of the bitstream slots."""
+        the host reading anything back (encode_batch_begin).  One small readback follows (sizes, coder status,
+        clamped-symbol count), then the copy of the used part of the bitstream slots (encode_batch_finish)."""
+        job = self.encode_batch_begin(input_image, entropy_coding)
+        if not entropy_coding:
+            if int(job["nclamp"].item()):
+                self._widen_tables()
+                return self.encode_batch(input_image, entropy_coding)
+            return job["sym"].view(job["B"], -1), job["idx"].view(job["B"], -1), job["h"], job["w"]
+        return self.encode_batch_finish(job)
+
+    def encode_batch_begin(self, input_image, entropy_coding=True):
+        """Enqueues the encoder's kernels on the current stream and returns at once.  -> a job for encode_batch_finish;
+        job["transforms_done"] is an event recorded behind g_a (what a pipelined caller orders other MFMA work after)."""
         self._ensure_tables()
         x = input_image.contiguous()
         B, M = x.shape[0], self.out_channel_M
@@ -301,38 +315,44 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         nbytes_d, status_d = meta[:2 * B].view(torch.int64), meta[2 * B:3 * B]
         geom_d, nclamp_d = meta[3 * B:3 * B + 2], meta[3 * B + 2:3 * B + 3]
         _, sym4, _ = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1, nclamp_d)
+        transforms_done = torch.cuda.Event()
+        transforms_done.record()
         _, h, w, _ = sym4.shape
         sym = sym4.view(-1, M)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_ln)
+        job = dict(input=input_image, B=B, h=h, w=w, sym=sym, idx=idx, nclamp=nclamp_d, transforms_done=transforms_done, dev=dev)
         if not entropy_coding:
-            if int(nclamp_d.item()):
-                self._widen_tables()
-                return self.encode_batch(input_image, entropy_coding)
-            return sym.view(B, -1), idx.view(B, -1), h, w
+            return job
         out, _, _, _ = ops.rans_encode_auto(self.entropy_table, idx, sym.reshape(-1), minbits, B, nbytes_d, status_d, geom_d)
-        host = self._meta_host(meta.numel())
+        host = self._meta_host(meta.numel(), "encode")
         host.copy_(meta, non_blocking=True)
         _mark("enc:enqueued")
+        job.update(out=out, meta=meta, host=host)
+        return job
+
+    def encode_batch_finish(self, job):
+        """Waits for the job's coder, brings the byte strings to the host.  Call it on the stream the job began on."""
+        B, dev, host, out = job["B"], job["dev"], job["host"], job["out"]
         torch.cuda.current_stream(dev).synchronize()                   # the one blocking readback before the bitstream copy
         _mark("enc:meta")
         hm = host.numpy()
         if int(hm[3 * B + 2]):
             self._widen_tables()                                       # like the reference (manynets_compressor.py:212-227)
-            return self.encode_batch(input_image, entropy_coding)
+            return self.encode_batch(job["input"], True)
         nb = hm[:2 * B].view(np.int64).tolist()
         st = hm[2 * B:3 * B].tolist()
         if min(st) < 0:
             raise _lib.MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
         self.last_stream_geometry = (int(hm[3 * B]), int(hm[3 * B + 1]))
         used = (max(nb) + 3) // 4 * 4
-        stage = self._staging(B * used)[:B * used]
+        stage = self._staging(B * used, "download")[:B * used]
         ops.download_rows(out, used, stage)
         torch.cuda.current_stream(dev).synchronize()
         _mark("enc:bytes_on_host")
         hb = stage.numpy().reshape(B, used)
         res = [hb[i, :nb[i]].tobytes() for i in range(B)]
         _mark("enc:strings")
-        return res, idx.view(B, -1), h, w
+        return res, job["idx"].view(B, -1), job["h"], job["w"]
 
     def encode(self, input_image, entropy_coding=True, out_fpath=None):
         """One image -> [bitstream, indices int64 [h*w,1], h, w] (manynets_compressor.py:197-290).  With
@@ -368,6 +388,13 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
 
         One host-to-device copy (sizes and strings together), then the coder and g_s are enqueued back to back; the
         decoder's status is read back while g_s runs and checked before the result is returned."""
+        job = self.decode_batch_begin(streams, idx, h, w)
+        self.decode_batch_synthesis(job)
+        return self.decode_batch_finish(job)
+
+    def decode_batch_begin(self, streams: List[bytes], idx, h: int, w: int):
+        """Copies the strings to the device and enqueues the coder on the current stream.  -> a job for
+        decode_batch_synthesis (enqueues g_s) and decode_batch_finish (checks the coder's status, returns x_hat)."""
         self._ensure_tables()
         B, M = len(streams), self.out_channel_M
         dev = self.entropy_table.device
@@ -377,7 +404,7 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         n_streams, lps = ops.parse_mrs1_headers(streams, h * w, M)
         stride = (max(len(s) for s in streams) + 3) // 4 * 4
         total = 8 * B + B * stride
-        stage = self._staging(total)[:total]
+        stage = self._staging(total, "upload")[:total]
         host = stage.numpy()
         host[:8 * B].view(np.int64)[:] = [len(s) for s in streams]
         rows = host[8 * B:].reshape(B, stride)                          # bytes past a stream's end are never read
@@ -389,18 +416,27 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         nbytes, data = buf[:8 * B].view(torch.int64), buf[8 * B:].view(B, stride)
         idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
         sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, lps)
-        st_host = self._meta_host(B)
+        st_host = self._meta_host(B, "decode")
         st_host.copy_(status, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        recon = self.Decoder.forward_nhwc(self.Decoder.latent_from_symbols(sym.view(B, h, w, M), self.min_feat, self.q_intv))
+        return dict(B=B, h=h, w=w, sym=sym, st_host=st_host, done=done, recon=None, keep=(buf, idx32, status))
+
+    def decode_batch_synthesis(self, job):
+        """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on)."""
+        B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
+        job["recon"] = self.Decoder.forward_nhwc(self.Decoder.latent_from_symbols(job["sym"].view(B, h, w, M), self.min_feat, self.q_intv))
         _mark("dec:enqueued")
-        done.synchronize()                                              # the coder has finished; g_s is still running
+        return job
+
+    def decode_batch_finish(self, job):
+        """Waits for the job's coder (not for g_s), checks its status, returns the reconstruction."""
+        job["done"].synchronize()                                       # the coder has finished; g_s may still be running
         _mark("dec:status")
-        st = st_host.tolist()
+        st = job["st_host"].tolist()
         if min(st) < 0:
             raise _lib.MpcError(f"corrupt MRS1 stream: decoder status {st}")
-        return recon
+        return job["recon"]
 
     def timing_analysis(self, input_image, entropy_coding=False, reps=50):
         """Mean seconds per stage under the reference's keys (manynets_compressor.py:383-500; caller tests.test_timing,

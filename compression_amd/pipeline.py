@@ -1,0 +1,82 @@
+"""Throughput mode of the codec: consecutive batches software-pipelined over two HIP streams.
+
+A codec step is g_a (MFMA-bound) -> prior competition and rANS encoder (latency-bound: a few thousand serial
+chains) -> byte strings on the host -> rANS decoder (latency-bound) -> g_s (MFMA-bound).  Run one batch after the
+other, the GPU idles through the latency-bound parts and the host round trip in the middle: a fifth of the step.  The
+batches are independent, so this driver keeps two in flight, each on its own stream, and orders the work so that
+
+    stream of batch n     : g_a(n) | competition, encoder(n) | (host: bytes of n) |  wait  | decoder(n) ...... | g_s(n)
+    stream of batch n - 1 : ......... | g_s(n-1) ........................................| g_a(n+1) .................
+
+the two transforms never run beside each other (g_s(n-1) waits for an event behind g_a(n); g_a(n+1) is enqueued behind
+g_s(n-1) on the same stream: two MFMA-bound kernels that share the CUs only slow each other, measured 12 % worse than
+no pipelining at all), the encoder runs beside g_s(n-1) and the decoder, held back until g_s(n-1) has ended, beside
+g_a(n+1).  Every batch still goes
+encode -> bytes on the host -> decode; only the order in which the host enqueues the phases changes
+(encode_batch_begin/finish, decode_batch_begin/synthesis/finish of the model).  The reference codes one image at a
+time on one stream (src/compression/tests.py:439-460); it has no counterpart of this driver.
+"""
+import torch
+
+
+class CodecPipeline:
+    def __init__(self, model, device, after_synthesis=None):
+        """after_synthesis(recon, strings, tag) -> anything: called right behind g_s with the batch's stream current
+        (e.g. clamp, squared error against the batch's target, statistics); its value comes back with the result."""
+        self.model = model
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        self.after_synthesis = after_synthesis
+        self.pending = None          # (decode job, stream, byte strings, tag) of the batch whose g_s is not enqueued yet
+        self.count = 0
+        for s in self.streams:       # whatever produced the inputs on the caller's stream comes first
+            s.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _complete(self, pending, transforms_done):
+        job, stream, strings, tag = pending
+        with torch.cuda.stream(stream):
+            if transforms_done is not None:
+                stream.wait_event(transforms_done)               # g_s(n-1) behind g_a(n)
+            self.model.decode_batch_synthesis(job)
+            extra = self.after_synthesis(job["recon"], strings, tag) if self.after_synthesis is not None else None
+            self.synthesis_done = torch.cuda.Event()
+            self.synthesis_done.record()
+        return job, stream, strings, tag, extra
+
+    def submit(self, x, tag=None):
+        """Encodes batch n (byte strings reach the host inside this call), starts its decoder, and finishes batch
+        n - 1.  -> None for the first batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1;
+        x_hat is complete on the stream `result_stream` (the caller's next use must be ordered behind it)."""
+        stream = self.streams[self.count & 1]
+        self.count += 1
+        with torch.cuda.stream(stream):
+            enc = self.model.encode_batch_begin(x)
+        done = self._complete(self.pending, enc["transforms_done"]) if self.pending is not None else None
+        with torch.cuda.stream(stream):
+            strings, idx, h, w = self.model.encode_batch_finish(enc)
+            if done is not None:
+                stream.wait_event(self.synthesis_done)           # decoder(n) behind g_s(n-1): it runs beside g_a(n+1)
+            dec = self.model.decode_batch_begin(strings, idx, h, w)
+        self.pending = (dec, stream, strings, tag)
+        return self._finish(done)
+
+    def _finish(self, done):
+        if done is None:
+            return None
+        job, stream, strings, tag, extra = done
+        with torch.cuda.stream(stream):
+            recon = self.model.decode_batch_finish(job)
+        self.result_stream = stream
+        return strings, recon, extra, tag
+
+    def flush(self):
+        """Finishes the batch still in flight (-> its result, or None if there is none)."""
+        if self.pending is None:
+            return None
+        done = self._complete(self.pending, None)
+        self.pending = None
+        return self._finish(done)
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

@@ -405,3 +405,37 @@ def test_timing_analysis_keys(model_fp16, dev):
     assert all(0.0 < v < 1.0 for v in td.values()), td
     bitstream, indices, h, w = model_fp16.encode(x)
     assert model_fp16.decode([bitstream, indices, h, w]).shape == (1, 3, 128, 192)
+
+
+def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev):
+    """Two batches in flight on two streams (CodecPipeline) give, batch for batch, the byte strings and the
+    reconstruction of encode_batch -> decode_batch run one after the other, at a size with several workgroups per CU
+    so that the phases really overlap."""
+    from compression_amd import ops
+    from compression_amd.pipeline import CodecPipeline
+    batches = [synth.rand_image(300 + i, 6, 256, 384).to(dev) for i in range(5)]
+    want = []
+    for x in batches:
+        strings, idx, h, w = model_fp16.encode_batch(x)
+        want.append((strings, model_fp16.decode_batch(strings, idx, h, w).clone()))
+    torch.cuda.synchronize()
+
+    def score(recon, strings, tag):
+        return ops.clamp_sse_per_image(recon, batches[tag])[1]
+
+    pipe = CodecPipeline(model_fp16, dev, after_synthesis=score)
+    got = []
+    for rep in range(2):                                   # the second round reuses every staging buffer
+        for i, x in enumerate(batches):
+            r = pipe.submit(x, tag=i)
+            if r is not None:
+                got.append(r)
+        got.append(pipe.flush())
+        pipe.synchronize()
+    assert [g[3] for g in got] == [0, 1, 2, 3, 4] * 2
+    for strings, recon, sse, tag in got:
+        assert strings == want[tag][0], f"batch {tag}: byte strings differ"
+        assert torch.equal(recon, want[tag][1]), f"batch {tag}: reconstruction differs"
+        ref_sse = ops.clamp_sse_per_image(want[tag][1], batches[tag])[1]
+        assert torch.allclose(sse, ref_sse, rtol=1e-12, atol=0.0)      # (fp64 atomics: the order of the partial sums varies)
+    assert pipe.flush() is None
