@@ -69,6 +69,8 @@ SIGNATURES = {
                                      c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mpc_rans_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
                                 c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mpc_rans_decode_latent_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
+                                           c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_rans_decode_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
                                         c_int64, c_int, c_int, c_void_p, c_void_p]),
     "mpc_conv_create": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),

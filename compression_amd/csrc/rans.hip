@@ -40,7 +40,16 @@ struct Geometry {
     uint32_t sps;           // symbols per stream = locs_per_stream * M
     uint32_t n_symbols;     // per image = n_loc * M
     uint32_t cap_words;     // sps + 2
+    int latent_f16 = 0;     // decoders: write fp16(symbol * lat_q + lat_min) (the latent g_s reads) instead of the symbol
+    int lat_min = 0, lat_q = 1;
 };
+
+// what a decoder stores for symbol s: the symbol itself, or the bits of the latent value as fp16 (exact for |v| <= 2048)
+__device__ __forceinline__ int16_t decoded_value(const Geometry &g, int s) {
+    if (!g.latent_f16) return (int16_t)s;
+    const _Float16 v = (_Float16)fminf(fmaxf((float)(s * g.lat_q + g.lat_min), -65504.0f), 65504.0f);
+    return __builtin_bit_cast(int16_t, v);
+}
 
 // Stream geometry chosen on the device (mpc_rans_encode_auto): ov = {n_streams, locs_per_stream} replaces the
 // host's values (which then only size the launch: grids cover the largest geometry, surplus threads leave).
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
                 ++wp;
                 wnext = (wp < wend) ? *wp : 0;
             }
-            if (t == 0) dst[i] = (int16_t)s;
+            if (t == 0) dst[i] = decoded_value(g, (int)s);
         }
         if (err) break;
     }
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
             if (t == (int)(n & 15)) mysym = s;
             if ((n & 15) == 15 || n + 1 == len) {
                 uint32_t first = n & ~15u;
-                if (first + t <= n) dst[b + first + t] = (int16_t)mysym;
+                if (first + t <= n) dst[b + first + t] = decoded_value(g, (int)mysym);
             }
         }
         heads = heads_nx;
@@ -784,6 +793,30 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
         if (!aligned) return MPC_EHIP;
     }
     rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+    if (L == 257) mpc_ctx_scratch_release(ctx);
+    return rc;
+}
+
+// The decoder's output as the fp16 latent g_s consumes (value = symbol * q_intv + min_feat, what
+// mpc_symbols_to_latent_f16 would make of mpc_rans_decode's symbols in one more pass over them).
+int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx, const uint8_t *in,
+                               size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int n_streams,
+                               int locs_per_stream, int min_feat, int q_intv, void *latent_f16_out, int32_t *status_dev) {
+    MPC_ENTER(ctx);
+    Geometry g;
+    int rc = rans_decode_check(ctx, g, table, K, M, L, idx, in, in_stride, nbytes_dev, n_images, n_loc, n_streams,
+                               locs_per_stream, (int16_t *)latent_f16_out, status_dev);
+    if (rc) return rc;
+    MPC_REQUIRE(ctx, q_intv > 0, "rans_decode_latent_f16: q_intv must be positive");
+    g.latent_f16 = 1;
+    g.lat_min = min_feat;
+    g.lat_q = q_intv;
+    void *aligned = nullptr;
+    if (L == 257) {
+        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * DMA_PITCH * sizeof(uint16_t));
+        if (!aligned) return MPC_EHIP;
+    }
+    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, (int16_t *)latent_f16_out, status_dev, aligned);
     if (L == 257) mpc_ctx_scratch_release(ctx);
     return rc;
 }

@@ -415,17 +415,24 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         buf.copy_(stage, non_blocking=True)
         nbytes, data = buf[:8 * B].view(torch.int64), buf[8 * B:].view(B, stride)
         idx32 = idx.to(device=dev, dtype=torch.int32).reshape(-1).contiguous()
-        sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, lps)
+        # with the fp16 synthesis transform the decoder writes the latent itself (no symbols -> latent pass)
+        direct = getattr(self.Decoder, "precision", None) == "fp16" and float(self.q_intv).is_integer()
+        if direct:
+            sym, status = ops.rans_decode_latent_f16(self.entropy_table, idx32, data, nbytes, B, n_streams, lps,
+                                                     self.min_feat, int(self.q_intv))
+        else:
+            sym, status = ops.rans_decode(self.entropy_table, idx32, data, nbytes, B, n_streams, lps)
         st_host = self._meta_host(B, "decode")
         st_host.copy_(status, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(B=B, h=h, w=w, sym=sym, st_host=st_host, done=done, recon=None, keep=(buf, idx32, status))
+        return dict(B=B, h=h, w=w, sym=sym, latent=direct, st_host=st_host, done=done, recon=None, keep=(buf, idx32, status))
 
     def decode_batch_synthesis(self, job):
         """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on)."""
         B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
-        job["recon"] = self.Decoder.forward_nhwc(self.Decoder.latent_from_symbols(job["sym"].view(B, h, w, M), self.min_feat, self.q_intv))
+        y = job["sym"].view(B, h, w, M)
+        job["recon"] = self.Decoder.forward_nhwc(y if job["latent"] else self.Decoder.latent_from_symbols(y, self.min_feat, self.q_intv))
         _mark("dec:enqueued")
         return job
 

@@ -389,6 +389,24 @@ def rans_decode(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbyt
     return sym, status
 
 
+def rans_decode_latent_f16(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int,
+                           n_streams: int, locs_per_stream: int, min_feat: int, q_intv: int):
+    """rans_decode whose output is the fp16 latent (symbol * q_intv + min_feat) the fp16 synthesis transform reads:
+    -> (latent fp16 [n_images, n_loc*M], status int32 [n_images])."""
+    _dev(table, torch.int16, "table"); _dev(idx, torch.int32, "idx"); _dev(data, torch.uint8, "data")
+    _dev(nbytes, torch.int64, "nbytes")
+    K, M, L = table.shape
+    n_loc = idx.numel() // n_images
+    dev = table.device
+    latent = torch.empty((n_images, n_loc * M), dtype=torch.float16, device=dev)
+    status = torch.empty(n_images, dtype=torch.int32, device=dev)
+    stride = data.shape[-1] if data.dim() == 2 else data.numel() // n_images
+    with _timed("rans_decode", symbols=n_images * n_loc * M):
+        context_for(dev).call("mpc_rans_decode_latent_f16", ptr(table), K, M, L, ptr(idx), ptr(data), stride, ptr(nbytes), n_images,
+                              n_loc, n_streams, locs_per_stream, int(min_feat), int(q_intv), ptr(latent), ptr(status))
+    return latent, status
+
+
 def rans_decode_noalloc(table: torch.Tensor, idx: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int,
                         n_streams: int, locs_per_stream: int, sym_out: torch.Tensor, status_out: torch.Tensor) -> None:
     """mpc_rans_decode_noalloc: the decode of rans_decode into caller-provided sym_out (int16 [n_images, n_loc*M]) and

@@ -197,6 +197,14 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
                     int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
                     int32_t *status_dev);
 
+/* mpc_rans_decode with the output written as the fp16 latent the synthesis transform reads: value =
+ * symbol * q_intv + min_feat (manynets_compressor.py:330 turns the decoded symbols into the latent with one more
+ * pass; here the decoder stores it directly).  latent_f16_out: n_images * n_loc * M fp16 values, NHWC. */
+int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
+                               const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
+                               int64_t n_loc, int n_streams, int locs_per_stream, int min_feat, int q_intv,
+                               void *latent_f16_out, int32_t *status_dev);
+
 /* Same as mpc_rans_decode, for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): it calls no allocating routine.  It has no counterpart in the
  * reference.  The aligned table copy lives in a static device array of the library instead of context scratch:
