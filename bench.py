@@ -395,7 +395,10 @@ def run_rank(args):
     def after_synthesis(recon, strings, tag):
         xhat, sse = ops.clamp_sse_per_image(recon, target)
         nbytes = float(sum(len(s) for s in strings))
-        a = accs.setdefault(torch.cuda.current_stream().cuda_stream, StatsAccumulator(device=dev))
+        key = torch.cuda.current_stream().cuda_stream
+        a = accs.get(key)
+        if a is None:
+            a = accs[key] = StatsAccumulator(device=dev)
         a.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
         a.all_reduce()
         state["acc"] = a

@@ -93,6 +93,20 @@ __global__ void nchw_to_nhwc_kernel(const float *__restrict__ in, int C, int HW,
     out[i] = c < C ? in[(b * C + c) * HW + hw] : 0.0f;
 }
 
+// The image case (3 planes -> 4-channel pixels): a thread makes two neighbouring pixels from three 8-byte loads, one
+// per plane, and writes them as 32 contiguous bytes.
+__global__ void nchw3_to_nhwc4_kernel(const float *__restrict__ in, int64_t HW, int64_t pairs_per_image, int64_t total_pairs,
+                                      float4 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_pairs) return;
+    const int64_t b = i / pairs_per_image, q = i - b * pairs_per_image;
+    const float *src = in + b * 3 * HW + 2 * q;
+    const float2 r = *(const float2 *)src, g = *(const float2 *)(src + HW), bl = *(const float2 *)(src + 2 * HW);
+    float4 *dst = out + b * HW + 2 * q;
+    dst[0] = make_float4(r.x, g.x, bl.x, 0.0f);
+    dst[1] = make_float4(r.y, g.y, bl.y, 0.0f);
+}
+
 __global__ void nhwc_to_nchw_kernel(const float *__restrict__ in, int C, int HW, int64_t total,
                                     float *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // index into [B][C][HW]
@@ -252,6 +266,13 @@ int mpc_nchw_to_nhwc(mpc_ctx *ctx, const float *in, int B, int C, int H, int W, 
     MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, in && out && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc: bad arguments");
     int64_t total = (int64_t)B * H * W * Cpad;
+    const int64_t HW = (int64_t)H * W;
+    if (C == 3 && Cpad == 4 && HW % 2 == 0 && ((uintptr_t)in % 8) == 0 && ((uintptr_t)out % 16) == 0) {
+        const int64_t pairs = B * (HW / 2);
+        nchw3_to_nhwc4_kernel<<<dim3((unsigned)mpc_cdiv(pairs, 256)), dim3(256), 0, ctx->stream>>>(in, HW, HW / 2, pairs, (float4 *)out);
+        MPC_CHECK_LAUNCH(ctx, "nchw_to_nhwc");
+        return MPC_OK;
+    }
     nchw_to_nhwc_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(in, C, H * W, Cpad, total, out);
     MPC_CHECK_LAUNCH(ctx, "nchw_to_nhwc");
     return MPC_OK;

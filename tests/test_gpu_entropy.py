@@ -179,6 +179,11 @@ def test_rans_encode_matches_spec_and_roundtrips(dev, ops, coder_case, n_streams
     dec, st = ops.rans_decode(table.to(dev), idx.reshape(-1).to(dev), out, nbytes, n_img, n_streams, lps)
     assert st.cpu().tolist() == [0] * n_img
     assert torch.equal(dec.cpu(), sym)
+    # the decoder writing the fp16 latent itself == its symbols put through symbols_to_latent_f16
+    lat, st = ops.rans_decode_latent_f16(table.to(dev), idx.reshape(-1).to(dev), out, nbytes, n_img, n_streams, lps, -127, 1)
+    assert st.cpu().tolist() == [0] * n_img
+    assert torch.equal(lat.view(-1), ops.symbols_to_latent_f16(dec.view(-1), -127, 1).view(-1))
+    assert torch.equal(lat.cpu().float(), sym.float() - 127.0)
 
 
 def test_rans_size_vs_range_coder(dev, ops, coder_case):
