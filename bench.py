@@ -14,6 +14,9 @@ One codec STEP =
     decode:  byte strings -> rANS decode -> latent -> g_s -> clamp -> x_hat on the device
     + per-image squared error and the batch's statistics vector (one 16-double all-reduce when N > 1)
 with the input batch already resident in HBM.  value = megapixels (B*H*W of the input) per second over all ranks.
+The codec workloads keep TWO batches in flight on two HIP streams (compression_amd/pipeline.py: step n's coders run
+beside the other batch's transforms; every batch still goes encode -> bytes on the host -> decode).  The timed region
+starts with nothing in flight and ends when all of its K batches are decoded.  --serial: one batch after the other.
 
 N GPUs: images are independent, every rank codes its own batch (weak scaling, no data-path collective).  Started as
 `python bench.py --gpus N` the script starts N child processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
@@ -24,8 +27,8 @@ Extra objects on the JSON line: "roofline" for the dominant kernel (achieved = a
 time by HIP events round each of its launches INSIDE the timed region, on the stream it runs on; the kernel is picked
 in the warm-up, where every launch carries events; traffic = bytes per launch from the committed counter passes, null
 if they were taken on other kernel sources), "kernels" (per-launch averages of all kernels: the dominant one from the
-timed region, the others from the same steps repeated after it with events round every launch -- ~40 events a step
-inside the timed region cost 0.6 ms of it and more, growing with the number of steps),
+timed region, the others from the same number of steps run after it one batch at a time with events round every
+launch -- ~40 events a step inside the timed region cost 0.6 ms of it and more, growing with the number of steps),
 "cdf_build" (the materialised per-symbol CDF rows at the workload's size, which the fused coder never needs),
 "hbm_ceiling" (device copy / fill rates measured in this run), "cpu_baseline" (the CPU oracle timed on this host),
 "stats" (the all-reduced evaluation statistics of one step), "device_allocs_in_timed_region" (hipMalloc calls of torch's
@@ -439,7 +442,8 @@ def run_rank(args):
 
     xhat = None
     wprof = ops.PROFILER = ops.Profiler()
-    for _ in range(max(args.warmup, 1)):
+    n_warm = max(args.warmup, 4 if pipe is not None else 1)   # (two batches per stream: torch's allocator has every block it will need)
+    for _ in range(n_warm):
         t = time.perf_counter()
         xhat = keep_last(step(), xhat)                      # (kept, as in the timed loop: the allocator reaches its steady state here)
         torch.cuda.synchronize()
@@ -461,10 +465,10 @@ def run_rank(args):
     ops.PROFILER = None
     timed_dom = prof.summary()[dom]
     # the other kernels' averages: the same steps once more, outside the timed region, every launch between events
+    # (one batch at a time here: with two in flight a kernel's event pair also spans what it waited for or ran beside)
     aprof = ops.PROFILER = ops.Profiler()
     for _ in range(args.steps):
-        xhat = keep_last(step(), xhat)
-    xhat = keep_last(drain(), xhat)
+        (serial_codec_step if args.mode == "codec" else forward_step)()
     ops.PROFILER = None
     kern = aprof.summary()
     kern[dom] = timed_dom
@@ -530,7 +534,7 @@ def run_rank(args):
                                f"random-init weights with spread priors, {args.data} input",
                    "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
                    "parallelism": f"image-sharded x{world}, statistics all-reduce only",
-                   "batches_in_flight": 2 if pipe is not None else 1},
+                   "batches_in_flight": 2 if pipe is not None else 1, "warmup_steps_run": n_warm},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,
