@@ -374,8 +374,9 @@ def run_rank(args):
 
     def serial_codec_step():
         streams, idx, h, w = model.encode_batch(x)
-        recon = model.decode_batch(streams, idx, h, w)
-        xhat, sse = ops.clamp_sse_per_image(recon, target)
+        job = model.decode_batch_begin(streams, idx, h, w)
+        model.decode_batch_synthesis(job, score_against=target)
+        xhat, sse = model.decode_batch_finish(job), job["sse"]
         nbytes = float(sum(len(s) for s in streams))
         acc.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
         acc.all_reduce()
@@ -395,8 +396,8 @@ def run_rank(args):
     # compression_amd/pipeline.py.  Each batch's statistics are formed behind its g_s on its own stream.
     accs = {}
 
-    def after_synthesis(recon, strings, tag):
-        xhat, sse = ops.clamp_sse_per_image(recon, target)
+    def after_synthesis(job, strings, tag):
+        xhat, sse = job["recon"], job["sse"]                # clamp and squared error come from the last layer's epilogue
         nbytes = float(sum(len(s) for s in strings))
         key = torch.cuda.current_stream().cuda_stream
         a = accs.get(key)
@@ -413,7 +414,7 @@ def run_rank(args):
         pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis)
 
     def pipelined_codec_step():
-        r = pipe.submit(x)
+        r = pipe.submit(x, target=target)
         return None if r is None else r[2]
 
     def drain():

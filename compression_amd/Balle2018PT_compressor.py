@@ -120,6 +120,12 @@ class Analysis_net(_FusedNet):
         return ops.nhwc_to_nchw(self.forward_nhwc(ops.nchw_to_nhwc(x.contiguous(), 4)))
 
 
+def _scored_last_layer(layer, t, target):
+    """-> (clamp(x_hat, 0, 1), per-image squared error against target): fused into the layer's epilogue if it can."""
+    fused = layer.forward_scored(t, target)
+    return fused if fused is not None else ops.clamp_sse_per_image(layer(t, nchw_out=True), target)
+
+
 class Synthesis_net(_FusedNet):
     """g_s: 4 x deconv 5x5 s2, IGDN after the first three (Balle2018PT_compressor.py:262-308)."""
 
@@ -141,13 +147,18 @@ class Synthesis_net(_FusedNet):
         return [(D, self.deconv1, 2, G, self.igdn1, False), (D, self.deconv2, 2, G, self.igdn2, False),
                 (D, self.deconv3, 2, G, self.igdn3, False), (D, self.deconv4, 2, _lib.MPC_ACT_NONE, None, False)]
 
-    def forward_nhwc(self, y):
+    def forward_nhwc(self, y, score_against=None):
         """y: NHWC fp32 latent -> NCHW fp32 image (unclamped).  With precision "fp16" (default) the four layers
-        run on fp16-operand MFMA with fp16 activations: x_hat stays within 1e-2 of the fp32 result."""
+        run on fp16-operand MFMA with fp16 activations: x_hat stays within 1e-2 of the fp32 result.
+        score_against (an NCHW fp32 image): -> (clamp(x_hat, 0, 1), float64 [B] squared errors against it), from the
+        last layer's epilogue where that kernel exists, else from one more pass."""
         l1, l2, l3, l4 = self.layers()
         if self.precision == "fp16" and y.dtype != torch.float16:
             y = ops.f32_to_f16(y)
-        return l4(l3(l2(l1(y))), nchw_out=True)
+        t = l3(l2(l1(y)))
+        if score_against is None:
+            return l4(t, nchw_out=True)
+        return _scored_last_layer(l4, t, score_against)
 
     def latent_from_symbols(self, sym, min_feat, q_intv):
         """int16 symbols NHWC -> the latent in the type this network's first layer takes."""

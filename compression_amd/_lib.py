@@ -78,6 +78,8 @@ SIGNATURES = {
     "mpc_conv_out_hw": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "mpc_conv_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_conv_forward_symbols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mpc_conv_scored_supported": (c_int, [c_void_p, c_int, c_int]),
+    "mpc_conv_forward_scored": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mpc_f32_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_f16_to_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "mpc_laplace_bits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -88,11 +88,10 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
     // ---- weights: chunk (tap, cb) of the packed image, through a ring of three chunks in LDS ----------------------
     // In the K loop a chunk travels global -> registers -> LDS: chunk c + 2 is loaded at the top of tap c and written
     // to the ring at the end of tap c + 1, so it has two taps to arrive and the only waits are the compiler's counted
-    // ones on its registers.  LDS-DMA is not used there: its pieces cannot be relied on to be in LDS, in issue order,
-    // when a counted s_waitcnt says so (a counted wait gave one wrong launch in 500 of the largest layer), and the
-    // vmcnt(0) that is safe also waits for the patch loads of the next block, which are meant to stay in flight for
-    // many taps (that wait cost 6 % of the layer).  The GDN steps have no other load in flight and keep LDS-DMA with
-    // a vmcnt(0) per step.
+    // ones on its registers.  LDS-DMA is not used there: a counted s_waitcnt does not tell that its pieces are in LDS
+    // (one wrong launch in 500 of the largest layer), and the full completion fence (lds_dma_fence) also waits for the
+    // patch loads of the next block, which are meant to stay in flight for many taps (that wait cost 6 % of the layer).
+    // The GDN steps have no other load in flight and keep LDS-DMA with a fence per step.
 #ifndef MPC_X3_STAGED_W
 #define MPC_X3_STAGED_W 1
 #endif
@@ -238,17 +237,17 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
                 }
-                MPC_WAIT_VMCNT(0);
+                lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
-        MPC_WAIT_VMCNT(0);                                // the surplus DMA pieces have landed before the LDS is reused
+        lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                                // the surplus DMA pieces have landed before the LDS is reused
         __syncthreads();
         x3_gdn_store<NF>(p, acc, nrm, (float4 *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
     } else {
-        MPC_WAIT_VMCNT(0);                                // no DMA is left in flight when the workgroup ends
+        lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                                // no DMA is left in flight when the workgroup ends
         if (!pvalid) return;
         x3_plain_store<NF>(p, acc, cg, h, opix);
     }
@@ -359,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             if (s < RGB_PR * RGB_ROW) patch[s] = __builtin_bit_cast(f4, two);
         }
     }
-    MPC_WAIT_VMCNT(0);
+    lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);
     __syncthreads();
     MPC_STAMP(1)
     MPC_STAMP_KBEGIN()
@@ -386,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        MPC_WAIT_VMCNT(0);                                                                                             \
+        lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);              \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         slot = slot == 2 ? 0 : slot + 1;                                                                               \
@@ -435,12 +434,12 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
         }
         bh = nh;
         bl = nl;
-        MPC_WAIT_VMCNT(0);
+        lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         slot = slot == 2 ? 0 : slot + 1;
     }
-    MPC_WAIT_VMCNT(0);                                    // the surplus DMA pieces have landed before the LDS is reused
+    lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                                    // the surplus DMA pieces have landed before the LDS is reused
     __syncthreads();
     MPC_STAMP(3)
     MPC_STAMP(4)

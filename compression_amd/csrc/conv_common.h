@@ -22,6 +22,25 @@ inline int64_t xcd_grid(int64_t blocks) { return (blocks + NUM_XCD - 1) / NUM_XC
 // s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
 #define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 #if defined(__HIPCC__)
+// Completion of this wave's LDS-DMA transfers (global_load_lds), to be followed by the workgroup's barrier.
+// vmcnt(0) alone is not enough: the counter drops when the data has come back from memory, and the write into LDS can
+// still be on its way -- another wave that passes the barrier then reads the old contents (seen as single wrong tiles,
+// a few per thousand launches, once other kernels shared the CUs; a delay of ~100 cycles in front of the barrier made
+// them disappear).  So the issuing wave reads a word of the area it has just had written, which the LDS serves behind
+// the wave's own DMA writes, waits for that read, and gives the write path a few more cycles.
+__device__ __forceinline__ void lds_dma_fence(const void *lds_written) {
+    __builtin_amdgcn_s_waitcnt(((0) & 15) | (((0) >> 4) << 14) | (7 << 4) | (15 << 8));       // vmcnt(0)
+#ifdef MPC_NO_DMA_FENCE                                    // (measurement builds only: what the fence costs)
+    return;
+#endif
+    unsigned probe;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(probe)
+                 : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)lds_written)
+                 : "memory");
+    __builtin_amdgcn_s_sleep(1);
+}
+
 __device__ __forceinline__ int64_t xcd_block() {
     const unsigned per = gridDim.x / NUM_XCD;
     return (int64_t)(blockIdx.x % NUM_XCD) * per + blockIdx.x / NUM_XCD;
@@ -67,6 +86,8 @@ struct Params {
     int sym_max;
     int *n_clamped;       // number of symbols that had to be clamped (may be null)
     const void *zeros;    // 256 bytes of zeros (what a tap outside the image reads)
+    const float *score_target;   // small-cout fp16 layer: NCHW fp32 image the clamped output is scored against (null: none)
+    double *score_sse;           // ... its per-image sums of squared errors, float64 [B], zeroed by the caller
     Phase ph[MAX_PHASES];
     int2 tapv[MAX_TAPS];  // the tap table by value: indexed with a uniform index it is read by scalar loads, which the
                           // vector-memory counter (and an LDS-DMA in flight) does not see
@@ -250,6 +271,7 @@ struct mpc_conv {
 int mpc_conv_launch_f16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);
 // fp16 last layer, cout <= 4 (conv_rgb_out_f16.hip)
 bool mpc_conv_rgb16_supported(int cin, int cout);
+bool mpc_conv_rgb16_rows_supported(int H, int W);
 size_t mpc_conv_rgb16_image_bytes(int cin);
 hipError_t mpc_conv_rgb16_pack(const float *weight, int cin, int cout, void *image, hipStream_t stream);
 int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c);

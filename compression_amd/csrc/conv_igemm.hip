@@ -694,7 +694,8 @@ int mpc_conv_out_hw(const mpc_conv *c, int H, int W, int *Ho, int *Wo) {
 
 // Body of mpc_conv_forward and mpc_conv_forward_symbols (sym == nullptr: no symbol output).
 static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int flags, void *out,
-                             float *out_round, int16_t *sym, int min_feat, int n_sym_values, int32_t *n_clamped_dev) {
+                             float *out_round, int16_t *sym, int min_feat, int n_sym_values, int32_t *n_clamped_dev,
+                             const float *score_target = nullptr, double *score_sse = nullptr) {
     MPC_REQUIRE(ctx, c && in && B > 0 && H > 0 && W > 0, "conv_forward: bad arguments");
     MPC_REQUIRE(ctx, c->device == ctx->device, "conv_forward: layer was created on another device");
     const mpc_conv_desc &d = c->desc;
@@ -717,6 +718,7 @@ static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, in
     p.in = in; p.out = out; p.out_round = want_round ? out_round : nullptr;
     p.out_sym = sym; p.sym_min_feat = (float)min_feat; p.sym_max = n_sym_values - 1; p.n_clamped = n_clamped_dev;
     p.zeros = c->bias + c->nf * c->groups * 32;
+    p.score_target = score_target; p.score_sse = score_sse;
     p.wpk = c->wpk; p.bias = c->bias; p.beta = c->beta; p.gamma = c->gamma; p.taps = c->taps;
     p.B = B; p.Hi = H; p.Wi = W; p.Cs = c->cin4 ? 4 : d.cin;
     p.Ho = Ho; p.Wo = Wo; p.sy = c->sy; p.sx = c->sx; p.my = c->my; p.mx = c->mx;
@@ -775,6 +777,22 @@ int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int
                      float *out_round) {
     MPC_ENTER(ctx);
     return conv_forward_impl(ctx, c, in, B, H, W, flags, out, out_round, nullptr, 0, 1, nullptr);
+}
+
+int mpc_conv_scored_supported(const mpc_conv *c, int H, int W) {
+    return c && c->f16 && c->stacked && c->wpk_rgb16 && c->desc.kind == MPC_DECONV && mpc_conv_rgb16_rows_supported(H, W) ? 1 : 0;
+}
+
+int mpc_conv_forward_scored(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, float *xhat_nchw,
+                            const float *target_nchw, double *sse_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, c && xhat_nchw && target_nchw && sse_dev, "conv_forward_scored: NULL argument");
+    MPC_REQUIRE(ctx, mpc_conv_scored_supported(c, H, W),
+                "conv_forward_scored: needs the fp16 small-cout transposed layer and an input width that is a multiple of 32 "
+                "(otherwise: mpc_conv_forward, then mpc_clamp_sse_batched)");
+    MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double) * B, ctx->stream));
+    return conv_forward_impl(ctx, c, in, B, H, W, MPC_OUT_NCHW | MPC_OUT_CLAMP01, xhat_nchw, nullptr, nullptr, 0, 1, nullptr,
+                             target_nchw, sse_dev);
 }
 
 int mpc_conv_forward_symbols(mpc_ctx *ctx, const mpc_conv *c, const void *in, int B, int H, int W, int min_feat,

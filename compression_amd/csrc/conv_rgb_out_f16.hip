@@ -174,10 +174,24 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(cons
     const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
     const int64_t t1 = (t0 + per_xcd < ntiles) ? t0 + per_xcd : ntiles;
     const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * ROWS_WAVES;
+    // scoring against a target image (p.score_target): squared error of this wave's outputs, summed per image
+    double sq_err = 0.0;
+    int err_image = -1;
+    auto flush_err = [&]() {
+        if (err_image >= 0) {
+            for (int off = 32; off > 0; off >>= 1) sq_err += __shfl_down(sq_err, off, 64);
+            if (lane == 0) atomicAdd(p.score_sse + err_image, sq_err);
+        }
+        sq_err = 0.0;
+    };
     for (int64_t t = t0 + (int64_t)(blockIdx.x / NUM_XCD) * ROWS_WAVES + wave; t < t1; t += stride) {
         const int x0 = (int)(t % tw) * ROWS_TILE;
         const int64_t rowid = t / tw;
         const int y = (int)(rowid % p.Hb), b = (int)(rowid / p.Hb);
+        if (p.score_target && b != err_image) {            // (wave-uniform: a tile lies in one image)
+            flush_err();
+            err_image = b;
+        }
         const int dy_lo = (y == 0) ? 0 : -1, dy_hi = (y == p.Hi - 1) ? 0 : 1;
         const int niter = (dy_hi - dy_lo + 1) * cb;
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -230,18 +244,27 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(cons
                         v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
                         v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
                     }
-                    float *o = out + (((int64_t)b * p.cout + kg) * p.Ho + 2 * y + yp) * p.Wo + 2 * (x0 + 16 * u + n);
-                    *(float2 *)o = make_float2(v0, v1);
+                    const int64_t oi = (((int64_t)b * p.cout + kg) * p.Ho + 2 * y + yp) * p.Wo + 2 * (x0 + 16 * u + n);
+                    *(float2 *)(out + oi) = make_float2(v0, v1);
+                    if (p.score_target) {
+                        const float2 tg = *(const float2 *)(p.score_target + oi);
+                        const float d0 = v0 - tg.x, d1 = v1 - tg.y;
+                        sq_err += (double)(d0 * d0) + (double)(d1 * d1);
+                    }
                 }
             }
         }
     }
+    if (p.score_target) flush_err();
 }
 
 }  // namespace
 
 // bytes of the packed A image
 size_t mpc_conv_rgb16_image_bytes(int cin) { return (size_t)9 * (cin / 64) * 2 * 64 * 16; }
+
+// the row-tiled kernel (the one that can score its output) takes whole 32-pixel runs of input rows
+bool mpc_conv_rgb16_rows_supported(int H, int W) { return H > 0 && W > 0 && W % ROWS_TILE == 0; }
 
 bool mpc_conv_rgb16_supported(int cin, int cout) {
     return cout >= 1 && cout <= 4 && cin % 64 == 0 && mpc_conv_rgb16_image_bytes(cin) <= 72 * 1024;

@@ -14,7 +14,8 @@
 // channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
 // streamed by LDS-DMA through a ring of three half chunks, two steps ahead; the next channel block's patch is brought
 // by LDS-DMA into the other patch buffer during the first steps of the current block.  No transfer passes through
-// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one s_waitcnt vmcnt(0), one s_barrier.
+// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one completion fence of the transfers
+// (lds_dma_fence), one s_barrier.
 //
 // LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
 // one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
@@ -137,7 +138,7 @@ struct Body {
         for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
         if (tid < COUT / 4) par[tid] = ((const f4 *)p.bias)[tid];
         if (EPI == EPI_GDN && tid >= 64 && tid < 64 + COUT / 4) par[COUT / 4 + tid - 64] = ((const f4 *)p.beta)[tid - 64];
-        MPC_WAIT_VMCNT(0);
+        lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);
         __syncthreads();
 
         // the accumulators start from the bias: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h
@@ -189,16 +190,15 @@ struct Body {
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
-            // Every transfer this wave has issued has landed before the barrier -- a full drain, not a counted wait
-            // that would leave this step's pieces in flight.  Counted waits (all but the youngest WPW + patch pieces)
-            // gave wrong values in a few tiles of the largest layer, a different few on every run (a determinism loop
-            // over 40 launches; the drain costs 2 %): with two workgroups per CU fetching the same weights, this
-            // kernel's LDS-DMA pieces did not complete in the order they were issued.
+            // Every transfer this wave has issued is in LDS before the barrier: the full completion fence, not a counted
+            // wait that would leave this step's pieces in flight.  Counted waits (all but the youngest WPW + patch
+            // pieces) gave wrong values in a few tiles of the largest layer on every run; vmcnt(0) alone still gave one
+            // wrong tile in ~6 % of the steps once another kernel's waves shared the CUs (see lds_dma_fence).
             MPC_SEG(1)
 #ifdef MPC_DP_COUNTED
             MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
 #else
-            MPC_WAIT_VMCNT(0);
+            lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
 #endif
             MPC_SEG(2)
             __builtin_amdgcn_s_barrier();
@@ -272,12 +272,12 @@ struct Body {
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
                 bv0 = bn0;
                 bv1 = bn1;
-                MPC_WAIT_VMCNT(0);
+                lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;
             }
-            MPC_WAIT_VMCNT(0);                            // the surplus DMA pieces have landed before the LDS is reused
+            lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                            // the surplus DMA pieces have landed before the LDS is reused
             __syncthreads();
             MPC_STAMP(3)
             // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
@@ -302,7 +302,7 @@ struct Body {
             ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
             MPC_STAMP(5)
         } else {
-            MPC_WAIT_VMCNT(0);                            // no DMA is left in flight when the workgroup ends
+            lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                            // no DMA is left in flight when the workgroup ends
             if (!pvalid) return;
             _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll

@@ -428,11 +428,17 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         done.record()
         return dict(B=B, h=h, w=w, sym=sym, latent=direct, st_host=st_host, done=done, recon=None, keep=(buf, idx32, status))
 
-    def decode_batch_synthesis(self, job):
-        """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on)."""
+    def decode_batch_synthesis(self, job, score_against=None):
+        """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on).  score_against (the
+        batch's original, NCHW fp32): the job's reconstruction is then clamp(x_hat, 0, 1) and job["sse"] holds the
+        per-image squared errors against it (float64 [B] on the device), both from the last layer's epilogue."""
         B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
         y = job["sym"].view(B, h, w, M)
-        job["recon"] = self.Decoder.forward_nhwc(y if job["latent"] else self.Decoder.latent_from_symbols(y, self.min_feat, self.q_intv))
+        y = y if job["latent"] else self.Decoder.latent_from_symbols(y, self.min_feat, self.q_intv)
+        if score_against is None:
+            job["recon"] = self.Decoder.forward_nhwc(y)
+        else:
+            job["recon"], job["sse"] = self.Decoder.forward_nhwc(y, score_against=score_against)
         _mark("dec:enqueued")
         return job
 

@@ -648,6 +648,28 @@ class ConvLayer:
             context_for(x.device).call("mpc_conv_forward", self.handle, ptr(x), B, H, W, flags, ptr(out), ptr(outr))
         return (out, outr) if round_out else out
 
+    def forward_scored(self, x: torch.Tensor, target: torch.Tensor):
+        """The last synthesis layer with the evaluation's clamp and squared error in its epilogue: -> (clamp(x_hat, 0, 1)
+        fp32 NCHW, float64 [B] sums of squared errors against `target`), or None when this layer / size has no such
+        kernel (then: the plain call followed by clamp_sse_per_image)."""
+        if not (self.f16 and self.small_cout):
+            return None
+        _dev(x, torch.float16, "x"); _dev(target, torch.float32, "target")
+        B, H, W, C = x.shape
+        if C != self.cin:
+            raise MpcError(f"input has {C} channels, layer expects {self.cin}")
+        if not self._lib.mpc_conv_scored_supported(self.handle, H, W):
+            return None
+        Ho, Wo = self.out_hw(H, W)
+        if tuple(target.shape) != (B, self.cout, Ho, Wo):
+            raise MpcError(f"forward_scored: target must be {(B, self.cout, Ho, Wo)}, got {tuple(target.shape)}")
+        xhat = torch.empty((B, self.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        sse = torch.empty(B, dtype=torch.float64, device=x.device)
+        self.kernel_name = "deconv_rgb16_kernel"
+        with _timed(self.kernel_name, flops=self.flops(B, H, W)):
+            context_for(x.device).call("mpc_conv_forward_scored", self.handle, ptr(x), B, H, W, ptr(xhat), ptr(target), ptr(sse))
+        return xhat, sse
+
     def forward_symbols(self, x: torch.Tensor, min_feat: int, n_sym_values: int, n_clamped: Optional[torch.Tensor] = None,
                         keep_rounded: bool = False):
         """The last analysis layer with quantisation and symbolisation fused: -> (round(y) fp32 NHWC | None, int16 symbols

@@ -21,31 +21,32 @@ import torch
 
 class CodecPipeline:
     def __init__(self, model, device, after_synthesis=None):
-        """after_synthesis(recon, strings, tag) -> anything: called right behind g_s with the batch's stream current
-        (e.g. clamp, squared error against the batch's target, statistics); its value comes back with the result."""
+        """after_synthesis(job, strings, tag) -> anything: called right behind g_s with the batch's stream current
+        (job["recon"]: the reconstruction; with a target given to submit() it is clamped and job["sse"] holds the
+        per-image squared errors); e.g. the batch's statistics.  Its value comes back with the result."""
         self.model = model
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
         self.after_synthesis = after_synthesis
-        self.pending = None          # (decode job, stream, byte strings, tag) of the batch whose g_s is not enqueued yet
+        self.pending = None          # (decode job, stream, byte strings, tag, target) of the batch whose g_s is not enqueued yet
         self.count = 0
         for s in self.streams:       # whatever produced the inputs on the caller's stream comes first
             s.wait_stream(torch.cuda.current_stream(self.device))
 
     def _complete(self, pending, transforms_done):
-        job, stream, strings, tag = pending
+        job, stream, strings, tag, target = pending
         with torch.cuda.stream(stream):
             if transforms_done is not None:
                 stream.wait_event(transforms_done)               # g_s(n-1) behind g_a(n)
-            self.model.decode_batch_synthesis(job)
-            extra = self.after_synthesis(job["recon"], strings, tag) if self.after_synthesis is not None else None
+            self.model.decode_batch_synthesis(job, score_against=target)
+            extra = self.after_synthesis(job, strings, tag) if self.after_synthesis is not None else None
             self.synthesis_done = torch.cuda.Event()
             self.synthesis_done.record()
         return job, stream, strings, tag, extra
 
-    def submit(self, x, tag=None):
+    def submit(self, x, tag=None, target=None):
         """Encodes batch n (byte strings reach the host inside this call), starts its decoder, and finishes batch
-        n - 1.  -> None for the first batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1;
+        n - 1.  target: the image batch n's reconstruction is to be scored against (see decode_batch_synthesis).  -> None for the first batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1;
         x_hat is complete on the stream `result_stream` (the caller's next use must be ordered behind it)."""
         stream = self.streams[self.count & 1]
         self.count += 1
@@ -57,7 +58,7 @@ class CodecPipeline:
             if done is not None:
                 stream.wait_event(self.synthesis_done)           # decoder(n) behind g_s(n-1): it runs beside g_a(n+1)
             dec = self.model.decode_batch_begin(strings, idx, h, w)
-        self.pending = (dec, stream, strings, tag)
+        self.pending = (dec, stream, strings, tag, target)
         return self._finish(done)
 
     def _finish(self, done):

@@ -272,6 +272,15 @@ int mpc_conv_out_hw(const mpc_conv *conv, int H, int W, int *Ho, int *Wo);
  * NULL) receives the unrounded values and `out_round` the rounded ones. */
 int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W,
                      int flags, void *out, float *out_round);
+/* The last layer of g_s with the evaluation's clamp and squared error fused into its epilogue: xhat_nchw =
+ * clamp(layer output, 0, 1) as fp32 NCHW and sse_dev[b] (device float64 [B], zeroed by this call) = sum over image b of
+ * (xhat - target)^2 -- recon.clamp(0, 1) and the per-image MSE of the test harness (manynets_compressor.py:537-543,
+ * tests.py:439-460) without a second pass over the image.  Available for the fp16 small-cout transposed layer at input
+ * widths that are multiples of 32 (mpc_conv_scored_supported returns 1); otherwise MPC_EINVAL: use mpc_conv_forward
+ * followed by mpc_clamp_sse_batched. */
+int mpc_conv_scored_supported(const mpc_conv *conv, int H, int W);
+int mpc_conv_forward_scored(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W, float *xhat_nchw,
+                            const float *target_nchw, double *sse_dev);
 /* The last layer of g_a with quantisation and symbolisation fused into its epilogue: a layer without activation on
  * the f32 or MPC_F16X3 path writes sym[pixel][c] = clamp(rint(conv + bias) - min_feat, 0, n_sym_values - 1) as int16
  * (NHWC = the reference's symbol order) and, if out_round is not NULL, rint(conv + bias) as fp32 NHWC.

@@ -420,8 +420,8 @@ def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev):
         want.append((strings, model_fp16.decode_batch(strings, idx, h, w).clone()))
     torch.cuda.synchronize()
 
-    def score(recon, strings, tag):
-        return ops.clamp_sse_per_image(recon, batches[tag])[1]
+    def score(job, strings, tag):
+        return ops.clamp_sse_per_image(job["recon"], batches[tag])[1]
 
     pipe = CodecPipeline(model_fp16, dev, after_synthesis=score)
     got = []
@@ -439,3 +439,20 @@ def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev):
         ref_sse = ops.clamp_sse_per_image(want[tag][1], batches[tag])[1]
         assert torch.allclose(sse, ref_sse, rtol=1e-12, atol=0.0)      # (fp64 atomics: the order of the partial sums varies)
     assert pipe.flush() is None
+
+
+@pytest.mark.parametrize("hw", [(128, 192), (64, 96)])      # last layer's input 96 wide (fused kernel) / 48 wide (extra pass)
+def test_scored_synthesis_matches_clamp_and_sse_pass(model_fp16, dev, hw):
+    """decode_batch_synthesis(score_against=x): clamp and per-image squared error from the last layer's epilogue equal
+    the reconstruction put through clamp_sse_per_image."""
+    from compression_amd import ops
+    x = synth.rand_image(77, 3, *hw).to(dev)
+    strings, idx, h, w = model_fp16.encode_batch(x)
+    recon = model_fp16.decode_batch(strings, idx, h, w)
+    want_xhat, want_sse = ops.clamp_sse_per_image(recon, x)
+    job = model_fp16.decode_batch_begin(strings, idx, h, w)
+    model_fp16.decode_batch_synthesis(job, score_against=x)
+    xhat = model_fp16.decode_batch_finish(job)
+    torch.cuda.synchronize()
+    assert torch.equal(xhat, want_xhat)
+    assert torch.allclose(job["sse"], want_sse, rtol=1e-10, atol=0.0)
