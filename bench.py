@@ -454,11 +454,19 @@ def run_rank(args):
     wk = wprof.summary()
     dom = max(conv_names(wk), key=lambda n: wk[n]["ms"])
     prof = ops.PROFILER = ops.Profiler(only={dom})
+    # A full pass of Python's cyclic collector over the ~10^6 objects that importing torch leaves behind takes 35-45 ms,
+    # and one fell into most timed regions (a single step of 43 ms among steps of 8.2 ms).  Collect now, then move
+    # everything that exists to the permanent generation: later passes only look at what the steps allocate.
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(args.steps):
         xhat = keep_last(step(), xhat)
+        marks.append(time.perf_counter())                   # (host time when the step's call returned: shows a stalled step)
     xhat = keep_last(drain(), xhat)                                  # ... and ends with all of its K batches decoded
     barrier()
     dt = time.perf_counter() - t0
@@ -549,6 +557,7 @@ def run_rank(args):
                             "locations": n_loc_probe, "bytes": n_loc_probe * 256 * 257 * 2}
     out["hbm_ceiling"] = hbm_ceiling(dev)
     out["device_allocs_in_timed_region"] = int(device_allocs)
+    out["host_ms_between_steps"] = [round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:])]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_images, 512, 768) if args.config == 3 else \
             cpu_baseline(max(2, min(args.cpu_images, int(16 * 393216 / (H * W)) or 2)), H, W)

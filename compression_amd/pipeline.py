@@ -5,13 +5,14 @@ chains) -> byte strings on the host -> rANS decoder (latency-bound) -> g_s (MFMA
 other, the GPU idles through the latency-bound parts and the host round trip in the middle: a fifth of the step.  The
 batches are independent, so this driver keeps two in flight, each on its own stream, and orders the work so that
 
-    stream of batch n     : g_a(n) | competition, encoder(n) | (host: bytes of n) |  wait  | decoder(n) ...... | g_s(n)
-    stream of batch n - 1 : ......... | g_s(n-1) ........................................| g_a(n+1) .................
+    stream of batch n     : g_a(n) | competition, encoder(n) | host: bytes of n | ........ wait ....... | decoder(n) | g_s(n)
+    stream of batch n - 1 : decoder(n-1) | wait | g_s(n-1) .....................| g_a(n+1) ............................
 
 the two transforms never run beside each other (g_s(n-1) waits for an event behind g_a(n); g_a(n+1) is enqueued behind
 g_s(n-1) on the same stream: two MFMA-bound kernels that share the CUs only slow each other, measured 12 % worse than
-no pipelining at all), the encoder runs beside g_s(n-1) and the decoder, held back until g_s(n-1) has ended, beside
-g_a(n+1).  Every batch still goes
+no pipelining at all), the encoder runs beside g_s(n-1), and the decoder of a batch, held back until the g_s before it
+has ended, beside the first layer of the next g_a (beside the second layer instead it costs the dominant kernel 9 % of
+its rate for 0.6 % of throughput).  Every batch still goes
 encode -> bytes on the host -> decode; only the order in which the host enqueues the phases changes
 (encode_batch_begin/finish, decode_batch_begin/synthesis/finish of the model).  The reference codes one image at a
 time on one stream (src/compression/tests.py:439-460); it has no counterpart of this driver.
@@ -28,14 +29,19 @@ class CodecPipeline:
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
         self.after_synthesis = after_synthesis
-        self.pending = None          # (decode job, stream, byte strings, tag, target) of the batch whose g_s is not enqueued yet
+        self.pending = None          # (byte strings, idx, h, w, stream, tag, target) of the batch that is encoded and not yet decoded
         self.count = 0
+        self.synthesis_done = None   # event behind the g_s (and hook) enqueued last
         for s in self.streams:       # whatever produced the inputs on the caller's stream comes first
             s.wait_stream(torch.cuda.current_stream(self.device))
 
-    def _complete(self, pending, transforms_done):
-        job, stream, strings, tag, target = pending
+    def _decode(self, undecoded, transforms_done):
+        """Enqueues decoder and g_s of the batch whose byte strings are on the host, each behind its event."""
+        strings, idx, h, w, stream, tag, target = undecoded
         with torch.cuda.stream(stream):
+            if self.synthesis_done is not None:
+                stream.wait_event(self.synthesis_done)           # decoder(n-1) behind g_s(n-2): beside the first layer of g_a(n)
+            job = self.model.decode_batch_begin(strings, idx, h, w)
             if transforms_done is not None:
                 stream.wait_event(transforms_done)               # g_s(n-1) behind g_a(n)
             self.model.decode_batch_synthesis(job, score_against=target)
@@ -45,20 +51,20 @@ class CodecPipeline:
         return job, stream, strings, tag, extra
 
     def submit(self, x, tag=None, target=None):
-        """Encodes batch n (byte strings reach the host inside this call), starts its decoder, and finishes batch
-        n - 1.  target: the image batch n's reconstruction is to be scored against (see decode_batch_synthesis).  -> None for the first batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1;
-        x_hat is complete on the stream `result_stream` (the caller's next use must be ordered behind it)."""
+        """Encodes batch n (its byte strings reach the host inside this call) and decodes batch n - 1.  target: the
+        image batch n's reconstruction is to be scored against (see decode_batch_synthesis).  -> None for the first
+        batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1; x_hat is complete on the stream
+        `result_stream` (the caller's next use must be ordered behind it)."""
         stream = self.streams[self.count & 1]
         self.count += 1
         with torch.cuda.stream(stream):
             enc = self.model.encode_batch_begin(x)
-        done = self._complete(self.pending, enc["transforms_done"]) if self.pending is not None else None
+        done = None
+        if self.pending is not None:
+            done = self._decode(self.pending, enc["transforms_done"])
         with torch.cuda.stream(stream):
             strings, idx, h, w = self.model.encode_batch_finish(enc)
-            if done is not None:
-                stream.wait_event(self.synthesis_done)           # decoder(n) behind g_s(n-1): it runs beside g_a(n+1)
-            dec = self.model.decode_batch_begin(strings, idx, h, w)
-        self.pending = (dec, stream, strings, tag, target)
+        self.pending = (strings, idx, h, w, stream, tag, target)
         return self._finish(done)
 
     def _finish(self, done):
@@ -71,10 +77,10 @@ class CodecPipeline:
         return strings, recon, extra, tag
 
     def flush(self):
-        """Finishes the batch still in flight (-> its result, or None if there is none)."""
+        """Decodes the batch still in flight (-> its result, or None if there is none)."""
         if self.pending is None:
             return None
-        done = self._complete(self.pending, None)
+        done = self._decode(self.pending, None)
         self.pending = None
         return self._finish(done)
 
