@@ -9,13 +9,12 @@
 // pixels and keeps the 18 x 10 patch around it, 32 input channels at a time, in LDS: the patch is fetched once per
 // channel block in whole 64-byte runs (1.4x the tile's bytes, the halo) and all taps read it with ds_read_b128.
 //
-// K walk: for each 32-channel block, the taps of this workgroup's phase.  One step = one tap x 32 channels = two
+// K walk: for each 32-channel block, the taps of this workgroup's phase, two per step.  One tap x 32 channels = two
 // k-steps of v_mfma_f32_32x32x16_f16 over the wave's NF output tiles (a wave = 2 tile rows = 32 pixels x all output
 // channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
-// streamed by LDS-DMA through a ring of three half chunks, two steps ahead; the next channel block's patch is brought
-// by LDS-DMA into the other patch buffer during the first steps of the current block.  No transfer passes through
-// registers, so a step is: a few DMA issues, 2 + 2 NF LDS reads, 2 NF MFMAs, one completion fence of the transfers
-// (lds_dma_fence), one s_barrier.
+// streamed by LDS-DMA one step ahead; the next channel block's patch is brought by LDS-DMA into the other patch buffer
+// during the steps of the current block.  No transfer passes through registers, so a step is: a few DMA issues,
+// 2 x (2 + 2 NF) LDS reads, 4 NF MFMAs, one completion fence of the transfers (lds_dma_fence), one s_barrier.
 //
 // LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
 // one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
@@ -35,9 +34,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-#ifndef MPC_DMA_AUX
-#define MPC_DMA_AUX 0
-#endif
 
 namespace {
 
@@ -49,20 +45,26 @@ constexpr int TILE_W = 16, TILE_H = 8, NW = 4, NT = 64 * NW;
 constexpr int PATCH_COLS = TILE_W + 2, PATCH_ROWS = TILE_H + 2;
 constexpr int PIX_F4 = 5;                            // slots per patch pixel (4 data + 1 padding)
 constexpr int ROW_F4 = 96;                           // slots per patch row (18 x 5 = 90 + 6 padding)
-constexpr int PATCH_PIECES = 16;                     // 1 KB DMA pieces per patch buffer (10 x 96 = 960 slots, rounded up)
-constexpr int PATCH_F4 = PATCH_PIECES * 64;
-constexpr int PPW = PATCH_PIECES / NW;               // patch pieces per wave
+constexpr int PPW = 4;                               // patch pieces (1 KB of DMA) per wave, at most
 
 __device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -HALF_MAX), HALF_MAX); }
 
-// patch pieces issued in step `tap` of a block with NTAPS taps: all PPW pieces go out in the first NTAPS - 2 steps
-// (a piece may stay in flight for two steps, and the block's last step must find the next patch complete)
-template <int NTAPS>
-__host__ __device__ constexpr int pieces_in_step(int tap) {
-    constexpr int per = (PPW + (NTAPS - 2) - 1) / (NTAPS - 2);
-    const int first = tap * per;
-    return tap < 0 ? 0 : (first >= PPW ? 0 : (first + per > PPW ? PPW - first : per));
+// A step multiplies TWO taps of the 32-channel block (4 NF MFMAs per wave) between one completion fence + barrier and
+// the next: with one tap per step the fence, the barrier's skew and the address arithmetic of a step were paid twice
+// as often (4 % of the layers).  The weights of a step (two half chunks, 24 KB for 192 output channels) are
+// double-buffered: the pair of step s + 1 is issued at the top of step s into the buffer that step s - 1 read.  The
+// patch buffers hold exactly the 10 x 96 slots of a patch (15 DMA pieces, the last wave brings 3), which keeps two
+// workgroups on a CU: 2 x 15 KB + 2 x 24 KB + 1.5 KB.
+constexpr int PATCH2_F4 = PATCH_ROWS * ROW_F4;           // 960 slots = 15 pieces of 1 KB
+constexpr int PATCH2_PIECES = PATCH2_F4 / 64;
+static_assert(PATCH2_PIECES * 64 == PATCH2_F4 && PATCH2_PIECES > (NW - 1) * PPW && PATCH2_PIECES <= NW * PPW, "patch pieces per wave");
+
+template <int NSTEPS>
+__host__ __device__ constexpr int pieces_in_step2(int k) {      // patch pieces a wave issues in step k of a block
+    constexpr int per = (PPW + NSTEPS - 1) / NSTEPS;
+    const int first = k * per;
+    return first >= PPW ? 0 : (first + per > PPW ? PPW - first : per);
 }
 
 template <int NF, int EPI>
@@ -71,17 +73,17 @@ struct Body {
     static constexpr int WCH_F4 = COUT * 4;              // slots of a half chunk (1 tap x 32 channels): [ks 2][h 2][cout]
     static constexpr int WPW = WCH_F4 / 64 / NW;         // 1 KB pieces of a half chunk that each wave brings
     static_assert(WPW * NW * 64 == WCH_F4, "a half chunk must split evenly into 1 KB pieces per wave");
+    static_assert(NF % 2 == 0, "gamma's half chunks go two per step");
 
     template <int NTAPS>
     static __device__ __forceinline__ void run(const Params &p, const Phase &ph, f4 *lds) {
-        f4 *patch = lds;                                 // 2 x PATCH_F4
-        f4 *wring = lds + 2 * PATCH_F4;                  // 3 x WCH_F4
-        f4 *par = wring + 3 * WCH_F4;                    // bias [COUT], beta [COUT] (beyond what the transposing store reuses)
+        constexpr int NSTEPS = (NTAPS + 1) / 2;          // steps per 32-channel block
+        f4 *patch = lds;                                 // 2 x PATCH2_F4
+        f4 *wring = lds + 2 * PATCH2_F4;                 // 2 buffers x 2 half chunks
+        f4 *par = wring + 4 * WCH_F4;                    // bias [COUT], beta [COUT] (beyond what the transposing store reuses)
 
         const int tid = threadIdx.x;
-        const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-        MPC_STAMP_DECL(blockIdx.y * gridDim.x + blockIdx.x)
-        MPC_STAMP(0)
+        const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
         const int tiles_x = (p.Wb + TILE_W - 1) / TILE_W, tiles_y = (p.Hb + TILE_H - 1) / TILE_H;
         const int64_t blk = xcd_block();
@@ -107,13 +109,14 @@ struct Body {
         }
         const _Float16 *zeros = (const _Float16 *)p.zeros;
         auto dma_patch = [&](int i, int cb, int buf) {   // piece i of this wave, channel block cb, into patch buffer buf
+            if (wave * PPW + i >= PATCH2_PIECES) return;  // (uniform: the last wave has one piece less)
             const _Float16 *src = soff[i] >= 0 ? in_b + soff[i] + cb * 32 : zeros;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(patch + buf * PATCH_F4 + (wave * PPW + i) * 64),
-                                             16, 0, MPC_DMA_AUX);
+                                             (__attribute__((address_space(3))) void *)(patch + buf * PATCH2_F4 + (wave * PPW + i) * 64),
+                                             16, 0, 0);
         };
 
-        // ---- weights: half chunk (tap, cb) of the packed image, then gamma's half chunks, by LDS-DMA ------------
+        // ---- weights: half chunks (tap, cb) of the packed image, then gamma's, two per step, by LDS-DMA ------------
         const int ncb = p.Cs / 32;                       // 32-channel blocks
         const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + ph.w_off);
         const f4 *gsrc = (const f4 *)p.gamma;
@@ -121,24 +124,25 @@ struct Body {
         auto w_half = [&](int tap, int cb) -> const f4 * {
             return wsrc + ((int64_t)(tap * (ncb >> 1) + (cb >> 1)) * 2 + (cb & 1)) * WCH_F4;
         };
-        auto dma_w = [&](const f4 *src, int slot) {
+        auto dma_half = [&](const f4 *src, int buf, int half) {
 #pragma unroll
             for (int q = 0; q < WPW; ++q) {
                 const int piece = wave * WPW + q;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
-                                                 (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, MPC_DMA_AUX);
+                                                 (__attribute__((address_space(3))) void *)(wring + (buf * 2 + half) * WCH_F4 + piece * 64), 16, 0, 0);
             }
         };
+        // what the fence reads back: the last piece this wave has had written into weight buffer buf
+        auto probe = [&](int buf) { return wring + buf * 2 * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane; };
 
-        // prologue: weights of steps 0 and 1, patch of block 0; bias and beta go to LDS, where the epilogue finds them
-        // without a trip to L2
-        dma_w(w_half(0, 0), 0);
-        dma_w(w_half(1, 0), 1);
+        // prologue: weights of step 0, patch of block 0; bias and beta go to LDS, where the epilogue finds them
+        dma_half(w_half(0, 0), 0, 0);
+        dma_half(w_half(1, 0), 0, 1);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
         if (tid < COUT / 4) par[tid] = ((const f4 *)p.bias)[tid];
         if (EPI == EPI_GDN && tid >= 64 && tid < 64 + COUT / 4) par[COUT / 4 + tid - 64] = ((const f4 *)p.beta)[tid - 64];
-        lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);
+        lds_dma_fence(probe(0));
         __syncthreads();
 
         // the accumulators start from the bias: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h
@@ -151,35 +155,15 @@ struct Body {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[f][4 * g + t] = bb[t];
             }
-        MPC_STAMP(1)
-        MPC_STAMP_KBEGIN()
 
         // this lane's pixel in the patch (tap (0,0) is patch row + 1, column + 1), piece h of each k-step
         const int lane_slot = (2 * wave + (j >> 4) + 1) * ROW_F4 + ((j & 15) + 1) * PIX_F4 + h;
-        int slot = 0;                                    // ring slot of the current half chunk; step + 2 goes to slot + 2 (mod 3)
+        int wbuf = 0;                                    // weight buffer of the current step
         int pbuf = 0;
 
-        // one step: tap TAP of the current 32-channel block
-        auto step = [&](auto tap_c, int cb, bool more) {
-            constexpr int TAP = decltype(tap_c)::value;
-            // weights two steps ahead: (TAP + 2, cb), or in the next block, or gamma's first half chunks
-            const f4 *nsrc = (TAP + 2 < NTAPS) ? w_half(TAP + 2, cb)
-                             : more            ? w_half(TAP + 2 - NTAPS, cb + 1)
-                             : (EPI == EPI_GDN) ? gsrc + (int64_t)(TAP + 2 - NTAPS) * WCH_F4
-                                                : wsrc;
-            // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
-            constexpr int first = TAP * ((PPW + (NTAPS - 2) - 1) / (NTAPS - 2));
-            auto issue = [&]() {
-                dma_w(nsrc, slot >= 1 ? slot - 1 : 2);
-#pragma unroll
-                for (int i = 0; i < pieces_in_step<NTAPS>(TAP); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
-            };
-            issue();
-            MPC_SEG(0)
-
-            const int2 d = p.tapv[ph.tap_off + TAP];     // uniform index: a scalar load from the kernel arguments
-            const f4 *bp = patch + pbuf * PATCH_F4 + lane_slot + d.x * ROW_F4 + d.y * PIX_F4;
-            const f4 *wl = wring + slot * WCH_F4 + h * COUT + j;
+        auto one_tap = [&](int tap, const f4 *wl) {
+            const int2 d = p.tapv[ph.tap_off + tap];     // uniform index: a scalar load from the kernel arguments
+            const f4 *bp = patch + pbuf * PATCH2_F4 + lane_slot + d.x * ROW_F4 + d.y * PIX_F4;
             const half8 b0 = as_half8(bp[0]), b1 = as_half8(bp[2]);
             half8 a[2][NF];
 #pragma unroll
@@ -190,51 +174,58 @@ struct Body {
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
 #pragma unroll
             for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
-            // Every transfer this wave has issued is in LDS before the barrier: the full completion fence, not a counted
-            // wait that would leave this step's pieces in flight.  Counted waits (all but the youngest WPW + patch
-            // pieces) gave wrong values in a few tiles of the largest layer on every run; vmcnt(0) alone still gave one
-            // wrong tile in ~6 % of the steps once another kernel's waves shared the CUs (see lds_dma_fence).
-            MPC_SEG(1)
-#ifdef MPC_DP_COUNTED
-            MPC_WAIT_VMCNT(WPW + pieces_in_step<NTAPS>(TAP) + pieces_in_step<NTAPS>(TAP - 1));
-#else
-            lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
-#endif
-            MPC_SEG(2)
+        };
+
+        // one step: taps 2K and 2K + 1 (if the phase has it) of the current 32-channel block
+        auto step = [&](auto k_c, int cb, bool more) {
+            constexpr int K = decltype(k_c)::value, T0 = 2 * K, T1 = 2 * K + 1;
+            // the next step's weights: in this block, in the next block, or gamma's first two half chunks
+            if constexpr (K + 1 < NSTEPS) {
+                dma_half(w_half(T0 + 2, cb), wbuf ^ 1, 0);
+                if constexpr (T0 + 3 < NTAPS) dma_half(w_half(T0 + 3, cb), wbuf ^ 1, 1);
+            } else {
+                if (more) {
+                    dma_half(w_half(0, cb + 1), wbuf ^ 1, 0);
+                    dma_half(w_half(1, cb + 1), wbuf ^ 1, 1);
+                } else if (EPI == EPI_GDN) {
+                    dma_half(gsrc, wbuf ^ 1, 0);
+                    dma_half(gsrc + WCH_F4, wbuf ^ 1, 1);
+                }
+            }
+            // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
+            constexpr int first = K * ((PPW + NSTEPS - 1) / NSTEPS);
+#pragma unroll
+            for (int i = 0; i < pieces_in_step2<NSTEPS>(K); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
+
+            const f4 *wl = wring + wbuf * 2 * WCH_F4 + h * COUT + j;
+            one_tap(T0, wl);
+            if constexpr (T1 < NTAPS) one_tap(T1, wl + WCH_F4);
+            lds_dma_fence(probe(wbuf ^ 1));              // everything this wave has issued is in LDS before the barrier
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            MPC_SEG(3)
-            slot = slot == 2 ? 0 : slot + 1;
+            wbuf ^= 1;
         };
 
         for (int cb = 0; cb < ncb; ++cb) {
             const bool more = cb + 1 < ncb;
             step(std::integral_constant<int, 0>{}, cb, more);
             step(std::integral_constant<int, 1>{}, cb, more);
-            step(std::integral_constant<int, 2>{}, cb, more);
-            step(std::integral_constant<int, 3>{}, cb, more);
-            if constexpr (NTAPS > 4) {
+            if constexpr (NSTEPS > 2) step(std::integral_constant<int, 2>{}, cb, more);
+            if constexpr (NSTEPS > 3) {
+                step(std::integral_constant<int, 3>{}, cb, more);
                 step(std::integral_constant<int, 4>{}, cb, more);
-                step(std::integral_constant<int, 5>{}, cb, more);
-            }
-            if constexpr (NTAPS > 6) {
-                step(std::integral_constant<int, 6>{}, cb, more);
-                step(std::integral_constant<int, 7>{}, cb, more);
-                step(std::integral_constant<int, 8>{}, cb, more);
             }
             pbuf ^= 1;
         }
 
-        MPC_STAMP(2)
-        MPC_STAMP_KEND()
         // ---- epilogue: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h of pixel (by, bx) --------------------
         const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
         if constexpr (EPI == EPI_GDN) {
             const bool inverse = p.act == MPC_ACT_IGDN;
-            // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF more steps: half chunk hc holds gamma[:, 32 hc .. 32 hc + 31]
-            // in the weight layout; the B operand is built from the lane's own accumulators, whose registers 8s..8s+7
-            // of tile hc are the 8 k-values of k-step s (c = 32 hc + 16 s + 8(jj>>2) + 4h + (jj&3)).  y^2 is scaled by
-            // 2^-8 and saturated before the conversion to fp16; the scale is undone on the fp32 sum.
+            // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF / 2 more steps of two half chunks: half chunk hc holds
+            // gamma[:, 32 hc .. 32 hc + 31] in the weight layout; the B operand is built from the lane's own accumulators,
+            // whose registers 8s..8s+7 of tile hc are the 8 k-values of k-step s (c = 32 hc + 16 s + 8(jj>>2) + 4h +
+            // (jj&3)).  y^2 is scaled by 2^-8 and saturated before the conversion to fp16; the scale is undone on the sum.
             f32x16 nrm[NF];                               // starts from beta (in the scale of the sum: 2^-8)
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -255,31 +246,36 @@ struct Body {
             };
             half8 bv0 = square(0, 0), bv1 = square(0, 1);
 #pragma unroll
-            for (int hc = 0; hc < NF; ++hc) {
-                dma_w(gsrc + (int64_t)(hc + 2 < NF ? hc + 2 : 0) * WCH_F4, slot >= 1 ? slot - 1 : 2);
-                const f4 *wl = wring + slot * WCH_F4 + h * COUT + j;
-                // the next step's operands are squared and converted while this step's MFMAs run
-                half8 bn0 = bv0, bn1 = bv1;
-                if (hc + 1 < NF) {
-                    bn0 = square(hc + 1, 0);
-                    bn1 = square(hc + 1, 1);
+            for (int g2 = 0; g2 < NF / 2; ++g2) {
+                if (g2 + 1 < NF / 2) {
+                    dma_half(gsrc + (int64_t)(2 * g2 + 2) * WCH_F4, wbuf ^ 1, 0);
+                    dma_half(gsrc + (int64_t)(2 * g2 + 3) * WCH_F4, wbuf ^ 1, 1);
                 }
 #pragma unroll
-                for (int fo = 0; fo < NF; ++fo)
-                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[fo * 32]), bv0, nrm[fo], 0, 0, 0);
+                for (int e = 0; e < 2; ++e) {
+                    const int hc = 2 * g2 + e;
+                    const f4 *wl = wring + (wbuf * 2 + e) * WCH_F4 + h * COUT + j;
+                    // the next half chunk's operands are squared and converted while this one's MFMAs run
+                    half8 bn0 = bv0, bn1 = bv1;
+                    if (hc + 1 < NF) {
+                        bn0 = square(hc + 1, 0);
+                        bn1 = square(hc + 1, 1);
+                    }
 #pragma unroll
-                for (int fo = 0; fo < NF; ++fo)
-                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
-                bv0 = bn0;
-                bv1 = bn1;
-                lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
+                    for (int fo = 0; fo < NF; ++fo)
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[fo * 32]), bv0, nrm[fo], 0, 0, 0);
+#pragma unroll
+                    for (int fo = 0; fo < NF; ++fo)
+                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
+                    bv0 = bn0;
+                    bv1 = bn1;
+                }
+                lds_dma_fence(probe(wbuf ^ 1));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                slot = slot == 2 ? 0 : slot + 1;
+                wbuf ^= 1;
             }
-            lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                            // the surplus DMA pieces have landed before the LDS is reused
-            __syncthreads();
-            MPC_STAMP(3)
+            __syncthreads();                              // (every transfer was fenced above: the LDS can be reused)
             // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
             // all output channels in one round); v_rsq_f32 is far more accurate than the fp16 output
             TransStore ts;
@@ -298,12 +294,9 @@ struct Body {
                     }
                     *(half4 *)ts.at(j, f * 64 + (8 * g + 4 * h) * 2) = o;
                 }
-            MPC_STAMP(4)
             ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
-            MPC_STAMP(5)
         } else {
-            lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                            // no DMA is left in flight when the workgroup ends
-            if (!pvalid) return;
+            if (!pvalid) return;                          // (the last step issued no transfer and fenced the others)
             _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll
             for (int f = 0; f < NF; ++f)
@@ -323,6 +316,7 @@ struct Body {
     }
 };
 
+
 template <int NF, int EPI>
 __global__ __launch_bounds__(NT, 2) void deconv5s2_patch_f16_kernel(const Params p) {
     extern __shared__ f4 lds[];
@@ -336,7 +330,7 @@ __global__ __launch_bounds__(NT, 2) void deconv5s2_patch_f16_kernel(const Params
 
 template <int NF, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase) {
-    size_t lds = ((size_t)2 * PATCH_F4 + 3 * (size_t)NF * 32 * 4 + 2 * NF * 8) * sizeof(f4);
+    size_t lds = ((size_t)2 * PATCH2_F4 + 4 * (size_t)NF * 32 * 4 + 2 * NF * 8) * sizeof(f4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
     auto kern = deconv5s2_patch_f16_kernel<NF, EPI>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
