@@ -150,6 +150,7 @@ struct TransStore {
     }
     template <int PIECES>
     __device__ __forceinline__ void flush(char *out, long long pixel_bytes, int col_off) const {
+        if constexpr (PIECES == 0) return;                // (a round with nothing left to write)
 #pragma unroll
         for (int i0 = 0; i0 < 32 * PIECES; i0 += 64) {
             const int i = i0 + lane;

@@ -498,7 +498,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
     const bool x3 = (d.flags & MPC_F16X3) != 0;
     MPC_REQUIRE(ctx, !(x3 && f16), "conv_create: MPC_F16 and MPC_F16X3 are exclusive");
     MPC_REQUIRE(ctx, !x3 || (!stacked && (cin4 ? d.cin == 3 : d.cin % 32 == 0) && (d.flags & MPC_IN_ABS) == 0),
-                "conv_create: the f16x3 path needs cin == 3 or cin % 32 == 0, cout % 32 == 0 and no MPC_IN_ABS");
+                "conv_create: the f16x3 path needs cin == 3 or a multiple of 32, cout a multiple of 32 and no MPC_IN_ABS");
     MPC_REQUIRE(ctx, !x3 || d.act == MPC_ACT_NONE || d.act == MPC_ACT_RELU || d.act == MPC_ACT_GDN || d.act == MPC_ACT_IGDN,
                 "conv_create: the f16x3 path supports no activation, ReLU, GDN and IGDN");
     MPC_REQUIRE(ctx, !f16 || (!cin4 && d.cin % 64 == 0), "conv_create: the fp16 path needs cin to be a multiple of 64");
