@@ -89,9 +89,9 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
     // In the K loop a chunk travels global -> registers -> LDS: chunk c + 2 is loaded at the top of tap c and written
     // to the ring at the end of tap c + 1, so it has two taps to arrive and the only waits are the compiler's counted
     // ones on its registers.  LDS-DMA is not used there: a counted s_waitcnt does not tell that its pieces are in LDS
-    // (one wrong launch in 500 of the largest layer), and the full completion fence (lds_dma_fence) also waits for the
+    // (one wrong launch in 500 of the largest layer), and the full wait (vmcnt(0), then dma_wait_last) also waits for the
     // patch loads of the next block, which are meant to stay in flight for many taps (that wait cost 6 % of the layer).
-    // The GDN steps have no other load in flight and keep LDS-DMA with a fence per step.
+    // The GDN steps have no other load in flight and keep LDS-DMA with an observed wait per step.
 #ifndef MPC_X3_STAGED_W
 #define MPC_X3_STAGED_W 1
 #endif
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
+            if (q == WPW - 1) dma_mark_last(wring + slot * WCH_F4 + piece * 64 + lane);   // the piece whose arrival is observed
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
                     nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
                 }
-                lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
+                dma_wait_last(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 slot = slot == 2 ? 0 : slot + 1;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
+            if (q == WPW - 1) dma_mark_last(wring + slot * WCH_F4 + piece * 64 + lane);   // the piece whose arrival is observed
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             if (s < RGB_PR * RGB_ROW) patch[s] = __builtin_bit_cast(f4, two);
         }
     }
-    lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);
+    dma_wait_last(wring + WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // (the second chunk was issued last)
     __syncthreads();
     MPC_STAMP(1)
     MPC_STAMP_KBEGIN()
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);              \
+        dma_wait_last(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);              \
         __builtin_amdgcn_s_barrier();                                                                                  \
         asm volatile("" ::: "memory");                                                                                 \
         slot = slot == 2 ? 0 : slot + 1;                                                                               \
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
         }
         bh = nh;
         bl = nl;
-        lds_dma_fence(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
+        dma_wait_last(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         slot = slot == 2 ? 0 : slot + 1;

@@ -22,23 +22,89 @@ inline int64_t xcd_grid(int64_t blocks) { return (blocks + NUM_XCD - 1) / NUM_XC
 // s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
 #define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 #if defined(__HIPCC__)
-// Completion of this wave's LDS-DMA transfers (global_load_lds), to be followed by the workgroup's barrier.
-// vmcnt(0) alone is not enough: the counter drops when the data has come back from memory, and the write into LDS can
-// still be on its way -- another wave that passes the barrier then reads the old contents (seen as single wrong tiles,
-// a few per thousand launches, once other kernels shared the CUs; a delay of ~100 cycles in front of the barrier made
-// them disappear).  So the issuing wave reads a word of the area it has just had written, which the LDS serves behind
-// the wave's own DMA writes, waits for that read, and gives the write path a few more cycles.
-__device__ __forceinline__ void lds_dma_fence(const void *lds_written) {
-    __builtin_amdgcn_s_waitcnt(((0) & 15) | (((0) >> 4) << 14) | (7 << 4) | (15 << 8));       // vmcnt(0)
-#ifdef MPC_NO_DMA_FENCE                                    // (measurement builds only: what the fence costs)
+// Completion of LDS-DMA transfers (global_load_lds), observed in the data.
+// vmcnt does not tell when an LDS-DMA transfer is in LDS: the counter drops when the data has come back from memory, and
+// the write into LDS can still be on its way, so another wave that passes the barrier can read the old contents.  Seen
+// as single wrong tiles, a few per thousand launches, once other kernels shared the CUs; delays in front of the barrier
+// (s_sleep, a read-back) made the errors rarer, not impossible.  So the arrival is observed.  A wave's transfers are
+// written in the order they were issued, so the LAST piece (64 lanes x 16 bytes) of a batch is watched: before that
+// piece is issued every lane marks the first and the last dword of its own 16 destination bytes with a value no operand
+// holds (two fp16 NaNs with every bit set: weights, gamma and activations are finite) and waits for those stores; the
+// wait for the batch is vmcnt(0) and then a poll of the marked dwords until no lane sees the mark.
+// What this does NOT cover: with a workgroup of ANOTHER transform kernel on the same CU (the last analysis layer run
+// beside the transposed layers) that other kernel's LDS was still hit, 4-11 times in 2 500 steps, and never with the
+// DMA-free kernel in the transposed layers' place.  CodecPipeline therefore never runs two transforms side by side;
+// beside the entropy coders' kernels 20 000 steps of 24 images were bit-identical.
+//   issue all pieces but the last;  dma_mark_last(lane's destination of the last piece);  issue it;  ...
+//   dma_wait_last(the same address);  barrier
+constexpr unsigned DMA_MARK = 0xFFFFFFFFu;
+typedef __attribute__((address_space(3))) volatile unsigned *lds_u32_ptr;
+
+// Two forms of the wait, chosen at build time (-DMPC_DMA_OBSERVE=1 | 0):
+//   1  the observed arrival described above: costs 11 % of the transposed layers (the marks must be in LDS before the
+//      last piece goes out);
+//   0  (default) vmcnt(0), a read of the watched piece's first dword by the issuing wave, 64 cycles of sleep: not a
+//      proof, but with it 20 000 pipelined steps were bit-identical as well, and it is 2.7 % of a codec step faster.
+#ifndef MPC_DMA_OBSERVE
+#define MPC_DMA_OBSERVE 0
+#endif
+__device__ __forceinline__ void dma_mark_last(void *lane_dst) {
+#if !MPC_DMA_OBSERVE
+    (void)lane_dst;
     return;
 #endif
-    unsigned probe;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                 : "=v"(probe)
-                 : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) const void *)lds_written)
-                 : "memory");
-    __builtin_amdgcn_s_sleep(1);
+    lds_u32_ptr q = (lds_u32_ptr)(__attribute__((address_space(3))) void *)lane_dst;
+    q[0] = DMA_MARK;
+    q[3] = DMA_MARK;
+    __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));              // lgkmcnt(0): the marks are in LDS
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void dma_wait_last(void *lane_dst) {
+    __builtin_amdgcn_s_waitcnt((0 & 15) | ((0 >> 4) << 14) | (7 << 4) | (15 << 8));               // vmcnt(0)
+    asm volatile("" ::: "memory");
+#ifdef MPC_NO_DMA_FENCE                                    // (measurement builds only: what the wait costs beyond vmcnt(0))
+    return;
+#endif
+#if !MPC_DMA_OBSERVE
+    {
+        unsigned probe;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                     : "=v"(probe)
+                     : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lane_dst)
+                     : "memory");
+        __builtin_amdgcn_s_sleep(1);
+        return;
+    }
+#endif
+    // The poll, as one opaque block (a loop in the source makes the register allocator spill the accumulators that are
+    // live across it): read the two marked dwords, leave when no lane sees the mark.  Bounded: a kernel must end even
+    // if an operand did hold the mark.
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lane_dst;
+    unsigned first, last;
+    unsigned long long seen;
+    int tries = 1 << 20;
+    asm volatile(
+        "1:\n\t"
+        "ds_read_b32 %0, %4\n\t"
+        "ds_read_b32 %1, %4 offset:12\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32_e32 vcc, -1, %0\n\t"
+        "v_cmp_eq_u32_e64 %2, -1, %1\n\t"
+        "s_or_b64 vcc, vcc, %2\n\t"
+        "s_sub_u32 %3, %3, 1\n\t"
+        "s_cmp_eq_u32 %3, 0\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cbranch_vccnz 1b\n\t"
+        "2:\n\t"
+        : "=&v"(first), "=&v"(last), "=&s"(seen), "+s"(tries)
+        : "v"(addr)
+        : "vcc", "scc", "memory");
+}
+
+// vmcnt(0) only: for waves that have issued nothing that needs watching
+__device__ __forceinline__ void lds_dma_fence(const void *) {
+    __builtin_amdgcn_s_waitcnt((0 & 15) | ((0 >> 4) << 14) | (7 << 4) | (15 << 8));
 }
 
 __device__ __forceinline__ int64_t xcd_block() {

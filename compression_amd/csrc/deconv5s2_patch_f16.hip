@@ -14,7 +14,7 @@
 // channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
 // streamed by LDS-DMA one step ahead; the next channel block's patch is brought by LDS-DMA into the other patch buffer
 // during the steps of the current block.  No transfer passes through registers, so a step is: a few DMA issues,
-// 2 x (2 + 2 NF) LDS reads, 4 NF MFMAs, one completion fence of the transfers (lds_dma_fence), one s_barrier.
+// 2 x (2 + 2 NF) LDS reads, 4 NF MFMAs, one observed wait for the transfers (dma_wait_last), one s_barrier.
 //
 // LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
 // one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
@@ -124,25 +124,27 @@ struct Body {
         auto w_half = [&](int tap, int cb) -> const f4 * {
             return wsrc + ((int64_t)(tap * (ncb >> 1) + (cb >> 1)) * 2 + (cb & 1)) * WCH_F4;
         };
-        auto dma_half = [&](const f4 *src, int buf, int half) {
+        // A batch of transfers is issued patch pieces first, then the second half chunk, then the first, whose last
+        // piece is the one whose arrival is observed (dma_mark_last / dma_wait_last): `watched`.
+        auto probe = [&](int buf) { return wring + buf * 2 * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane; };
+        auto dma_half = [&](const f4 *src, int buf, int half, bool watched = false) {
 #pragma unroll
             for (int q = 0; q < WPW; ++q) {
                 const int piece = wave * WPW + q;
+                if (watched && q == WPW - 1) dma_mark_last(probe(buf));
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
                                                  (__attribute__((address_space(3))) void *)(wring + (buf * 2 + half) * WCH_F4 + piece * 64), 16, 0, 0);
             }
         };
-        // what the fence reads back: the last piece this wave has had written into weight buffer buf
-        auto probe = [&](int buf) { return wring + buf * 2 * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane; };
 
         // prologue: weights of step 0, patch of block 0; bias and beta go to LDS, where the epilogue finds them
-        dma_half(w_half(0, 0), 0, 0);
-        dma_half(w_half(1, 0), 0, 1);
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
+        dma_half(w_half(1, 0), 0, 1);
+        dma_half(w_half(0, 0), 0, 0, true);
         if (tid < COUT / 4) par[tid] = ((const f4 *)p.bias)[tid];
         if (EPI == EPI_GDN && tid >= 64 && tid < 64 + COUT / 4) par[COUT / 4 + tid - 64] = ((const f4 *)p.beta)[tid - 64];
-        lds_dma_fence(probe(0));
+        dma_wait_last(probe(0));
         __syncthreads();
 
         // the accumulators start from the bias: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h
@@ -179,28 +181,27 @@ struct Body {
         // one step: taps 2K and 2K + 1 (if the phase has it) of the current 32-channel block
         auto step = [&](auto k_c, int cb, bool more) {
             constexpr int K = decltype(k_c)::value, T0 = 2 * K, T1 = 2 * K + 1;
-            // the next step's weights: in this block, in the next block, or gamma's first two half chunks
-            if constexpr (K + 1 < NSTEPS) {
-                dma_half(w_half(T0 + 2, cb), wbuf ^ 1, 0);
-                if constexpr (T0 + 3 < NTAPS) dma_half(w_half(T0 + 3, cb), wbuf ^ 1, 1);
-            } else {
-                if (more) {
-                    dma_half(w_half(0, cb + 1), wbuf ^ 1, 0);
-                    dma_half(w_half(1, cb + 1), wbuf ^ 1, 1);
-                } else if (EPI == EPI_GDN) {
-                    dma_half(gsrc, wbuf ^ 1, 0);
-                    dma_half(gsrc + WCH_F4, wbuf ^ 1, 1);
-                }
-            }
             // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
             constexpr int first = K * ((PPW + NSTEPS - 1) / NSTEPS);
 #pragma unroll
             for (int i = 0; i < pieces_in_step2<NSTEPS>(K); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
+            // the next step's weights: in this block, in the next block, or gamma's first two half chunks
+            if constexpr (K + 1 < NSTEPS) {
+                if constexpr (T0 + 3 < NTAPS) dma_half(w_half(T0 + 3, cb), wbuf ^ 1, 1);
+                dma_half(w_half(T0 + 2, cb), wbuf ^ 1, 0, true);
+            } else {
+                // (the very last step of a layer without GDN has nothing to bring but may carry patch pieces: its first
+                // half chunk is fetched once more, as the watched end of the batch)
+                const f4 *n0 = more ? w_half(0, cb + 1) : (EPI == EPI_GDN ? gsrc : w_half(0, cb));
+                const f4 *n1 = more ? w_half(1, cb + 1) : (EPI == EPI_GDN ? gsrc + WCH_F4 : w_half(1, cb));
+                dma_half(n1, wbuf ^ 1, 1);
+                dma_half(n0, wbuf ^ 1, 0, true);
+            }
 
             const f4 *wl = wring + wbuf * 2 * WCH_F4 + h * COUT + j;
             one_tap(T0, wl);
             if constexpr (T1 < NTAPS) one_tap(T1, wl + WCH_F4);
-            lds_dma_fence(probe(wbuf ^ 1));              // everything this wave has issued is in LDS before the barrier
+            dma_wait_last(probe(wbuf ^ 1));              // everything this wave has issued is in LDS before the barrier
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             wbuf ^= 1;
@@ -248,8 +249,8 @@ struct Body {
 #pragma unroll
             for (int g2 = 0; g2 < NF / 2; ++g2) {
                 if (g2 + 1 < NF / 2) {
-                    dma_half(gsrc + (int64_t)(2 * g2 + 2) * WCH_F4, wbuf ^ 1, 0);
                     dma_half(gsrc + (int64_t)(2 * g2 + 3) * WCH_F4, wbuf ^ 1, 1);
+                    dma_half(gsrc + (int64_t)(2 * g2 + 2) * WCH_F4, wbuf ^ 1, 0, true);
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -270,7 +271,7 @@ struct Body {
                     bv0 = bn0;
                     bv1 = bn1;
                 }
-                lds_dma_fence(probe(wbuf ^ 1));
+                if (g2 + 1 < NF / 2) dma_wait_last(probe(wbuf ^ 1));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 wbuf ^= 1;
@@ -296,7 +297,7 @@ struct Body {
                 }
             ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
         } else {
-            if (!pvalid) return;                          // (the last step issued no transfer and fenced the others)
+            if (!pvalid) return;                          // (every step has waited for its own transfers)
             _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll
             for (int f = 0; f < NF; ++f)
