@@ -94,15 +94,18 @@ class Analysis_net(_FusedNet):
             t = l3(l2(l1(x4)))
         return l4(t, round_out=round_out, keep_unrounded=keep_unrounded)
 
-    def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False):
+    def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False, events=None):
         """x4 -> (round(y) | None, int16 symbols NHWC, clamped count): quantisation and symbolisation run in the last
-        layer's epilogue."""
+        layer's epilogue.  events (a dict): receives "layer3_done", an event recorded behind the third layer."""
         l1, l2, l3, l4 = self.layers()
         if self.precision == "f16x3":
             self._check_split_range()
             t = l3(l2(l1(x4, out_split=True), out_split=True), out_split=True)
         else:
             t = l3(l2(l1(x4)))
+        if events is not None:
+            events["layer3_done"] = torch.cuda.Event()
+            events["layer3_done"].record()
         return l4.forward_symbols(t, min_feat, n_sym_values, n_clamped, keep_rounded)
 
     def _check_split_range(self):

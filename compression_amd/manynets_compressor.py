@@ -20,6 +20,9 @@ from .Balle2018PT_compressor import Analysis_net, Synthesis_net
 from .bitEstimator import MultiHeadBitEstimator
 
 TRY_PNG_SIDESTRING = True      # pt_helpers.get_num_bits(try_png=...) for bpp_sidestring
+# Stress knob for tests of the LDS-DMA hazard: a pipelined caller then starts g_s(n-1) behind the THIRD layer of g_a(n),
+# so that the first transposed layers run beside the last analysis layer (wrong tiles, a few per thousand steps).
+STRESS_OVERLAP_TRANSFORMS = False
 HOST_TRACE = None              # a list: encode_batch / decode_batch append (label, time.perf_counter()) at their host-side milestones
 
 
@@ -314,9 +317,13 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         meta = torch.empty(3 * B + 4, dtype=torch.int32, device=dev)
         nbytes_d, status_d = meta[:2 * B].view(torch.int64), meta[2 * B:3 * B]
         geom_d, nclamp_d = meta[3 * B:3 * B + 2], meta[3 * B + 2:3 * B + 3]
-        _, sym4, _ = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1, nclamp_d)
+        events = {}
+        _, sym4, _ = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1, nclamp_d,
+                                                  events=events)
         transforms_done = torch.cuda.Event()
         transforms_done.record()
+        if STRESS_OVERLAP_TRANSFORMS:
+            transforms_done = events["layer3_done"]
         _, h, w, _ = sym4.shape
         sym = sym4.view(-1, M)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_ln)
