@@ -13,6 +13,7 @@
 // The x-parity pair of a row pair lands in consecutive accumulator registers of one lane: the output is
 // written as float2, 128 contiguous bytes per 16 lanes.
 #include "conv_common.h"
+#include <type_traits>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -135,18 +136,35 @@ __global__ __launch_bounds__(64 * RGB16_WAVES, 2) void deconv_rgb16_kernel(const
     }
 }
 
-// Variant for base grids whose width is a multiple of 32 (every size the codec pads to): a wave owns 32
-// consecutive pixels of ONE image row, so for each input row offset dy and 64-channel chunk it stages the 34
-// input pixels x0-1 .. x0+32 once, in full 128-byte lines, into a wave-private LDS tile and reads the B operands
-// of the three horizontal taps from there at shifted positions: a third of the vector-memory traffic of the
-// direct form, and whole cache lines per load instruction.  Tile layout: [pixel 34][8 pieces of 16 bytes],
-// piece q of pixel p at column q ^ (p & 7) (conflict-free for the 16-byte reads of 16 consecutive pixels).
+// Variant for base grids whose width is a multiple of 32 (every size the codec pads to): a wave owns a strip of 32
+// columns.  For an input row and 64-channel chunk it stages the 34 input pixels x0-1 .. x0+32 once, in full
+// 128-byte lines, into a wave-private LDS tile and reads the B operands of the three horizontal taps from there at
+// shifted positions: a third of the vector-memory traffic of the direct form, and whole cache lines per load
+// instruction.  Tile layout: [pixel 34][8 pieces of 16 bytes], piece q of pixel p at column q ^ (p & 7)
+// (conflict-free for the 16-byte reads of 16 consecutive pixels).
+//
+// The wave walks DOWN its strip over a segment of consecutive output rows: an input row is staged once and
+// multiplied into the three output rows it belongs to (three accumulator sets, 24 registers); when input row r is
+// done, output row r - 1 is complete and is written.  (One output row per tile, each input row then fetched by
+// three tiles at three different times, moved 2.7x the input through the fabric: the 4 MB L2 of an XCD does not
+// hold what its 512 waves stream in between.  0.39 -> 0.25 ms on 24 x 192 x 256 x 384.)  Input traffic is
+// (rows + 2) / rows of the compulsory bytes, LDS operand reads a third per MFMA.  The launch picks the rows per
+// segment so that all segments fit ONE round of the persistent grid where the image allows it (a second, partly
+// filled round costs more than the longer walk): strip_rows() below.
 constexpr int ROWS_WAVES = 16;
 constexpr int ROWS_TILE = 32;
 constexpr int ROWS_STAGE_F4 = 34 * 8;      // 16-byte slots of one staging tile
+constexpr int STRIP_ROWS_MIN = 4, STRIP_ROWS_MAX = 32;
+
+inline int strip_rows(int64_t strips, int Hb) {
+    int64_t segs = (int64_t)NUM_CU * ROWS_WAVES / (strips > 0 ? strips : 1);   // segments per strip that fit one round
+    if (segs < 1) segs = 1;
+    int64_t rows = (Hb + segs - 1) / segs;
+    return (int)(rows < STRIP_ROWS_MIN ? STRIP_ROWS_MIN : rows > STRIP_ROWS_MAX ? STRIP_ROWS_MAX : rows);
+}
 
 __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(const Params p, const float4 *__restrict__ wimg,
-                                                                             int nsteps, int64_t ntiles) {
+                                                                               int nsteps, int64_t nunits, int seg_rows) {
     extern __shared__ float4 lds[];                        // nsteps * 128 weights, then ROWS_WAVES staging tiles
     const int tid = threadIdx.x;
     for (int i = tid; i < nsteps * 128; i += 64 * ROWS_WAVES) lds[i] = wimg[i];
@@ -158,24 +176,14 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(cons
     const _Float16 *in = (const _Float16 *)p.in;
     float *out = (float *)p.out;
     const bool clamp01 = (p.flags & MPC_OUT_CLAMP01) != 0;
-    const int tw = p.Wb / ROWS_TILE;                       // tiles per row
+    const int tw = p.Wb / ROWS_TILE;                       // strips per row
+    const int segs = (p.Hb + seg_rows - 1) / seg_rows;     // segments per strip
 
-    // staging role of this lane: pieces j = lane + 64 i of the 34 x 8 tile
-    int spx[5], slot[5], sq[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        int j = lane + 64 * i;
-        spx[i] = j >> 3;
-        sq[i] = j & 7;
-        slot[i] = spx[i] * 8 + (sq[i] ^ (spx[i] & 7));
-    }
-    // B-operand role: pixel n of sub-tile u, k-group kg; tile pixel index 1 + 16u + n + dx
-    const int64_t per_xcd = (ntiles + NUM_XCD - 1) / NUM_XCD;
-    const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
-    const int64_t t1 = (t0 + per_xcd < ntiles) ? t0 + per_xcd : ntiles;
-    const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * ROWS_WAVES;
-    // scoring against a target image (p.score_target): squared error of this wave's outputs, summed per image
-    double sq_err = 0.0;
+    // staging role of this lane: pieces j = lane + 64 i of the 34 x 8 tile, i.e. piece sq of pixels sp0 + 8 i
+    const int sp0 = lane >> 3, sq = lane & 7;
+    const int slot0 = sp0 * 8 + (sq ^ sp0);                // (sp0 + 8 i) & 7 == sp0; slot of pixel sp0 + 8 i is slot0 + 64 i
+    const bool fifth = sp0 < 2;                            // pixels 32, 33
+    double sq_err = 0.0;                                   // scoring against p.score_target, per image
     int err_image = -1;
     auto flush_err = [&]() {
         if (err_image >= 0) {
@@ -184,75 +192,117 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(cons
         }
         sq_err = 0.0;
     };
+
+    const int64_t per_xcd = (nunits + NUM_XCD - 1) / NUM_XCD;
+    const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
+    const int64_t t1 = (t0 + per_xcd < nunits) ? t0 + per_xcd : nunits;
+    const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * ROWS_WAVES;
     for (int64_t t = t0 + (int64_t)(blockIdx.x / NUM_XCD) * ROWS_WAVES + wave; t < t1; t += stride) {
+        // unit t = (image, segment, strip), strips of one segment next to each other
         const int x0 = (int)(t % tw) * ROWS_TILE;
-        const int64_t rowid = t / tw;
-        const int y = (int)(rowid % p.Hb), b = (int)(rowid / p.Hb);
-        if (p.score_target && b != err_image) {            // (wave-uniform: a tile lies in one image)
+        const int64_t rest = t / tw;
+        const int seg = (int)(rest % segs), b = (int)(rest / segs);
+        const int y0 = seg * seg_rows, y1 = (y0 + seg_rows < p.Hb) ? y0 + seg_rows : p.Hb;         // output rows [y0, y1)
+        const int r0 = (y0 > 0) ? y0 - 1 : 0, r1 = (y1 < p.Hi) ? y1 : p.Hi - 1;                    // input rows [r0, r1]
+        if (p.score_target && b != err_image) {            // (wave-uniform)
             flush_err();
             err_image = b;
         }
-        const int dy_lo = (y == 0) ? 0 : -1, dy_hi = (y == p.Hi - 1) ? 0 : 1;
-        const int niter = (dy_hi - dy_lo + 1) * cb;
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[3][2];                                   // output row y lives in set y % 3
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k][0] = acc[k][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        auto load_stage = [&](int it, float4 (&dst)[5]) {
-            const int dyi = it / cb, chunk = it - dyi * cb;
-            const _Float16 *rowp = in + (((int64_t)b * p.Hi + y + dy_lo + dyi) * p.Wi + x0 - 1) * p.Cs + chunk * 64;
+        auto load_stage = [&](int r, int chunk, float4 (&dst)[5]) {
+            const _Float16 *lanep = in + (((int64_t)b * p.Hi + r) * p.Wi + x0 - 1 + sp0) * p.Cs + chunk * 64 + sq * 8;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                const int gx = x0 - 1 + spx[i];
+                const int gx = x0 - 1 + sp0 + 8 * i;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((i < 4 || spx[i] < 34) && gx >= 0 && gx < p.Wi) v = *(const float4 *)(rowp + (int64_t)spx[i] * p.Cs + sq[i] * 8);
+                if ((i < 4 || fifth) && gx >= 0 && gx < p.Wi) v = *(const float4 *)(lanep + (int64_t)(8 * i) * p.Cs);
                 dst[i] = v;
             }
         };
-        float4 sreg[5];
-        load_stage(0, sreg);
-        for (int it = 0; it < niter; ++it) {
+        auto store_row = [&](int y, const f32x4 (&a)[2]) {
+            // lane (n, kg) holds rows 4kg..4kg+3 of pixel n: (co, ypar) = (kg, 0) in registers 0,1 and (kg, 1) in 2,3
+            if (kg < p.cout) {
+                const float bias = p.bias[kg];
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
-                if (i < 4 || spx[i] < 34) stage[slot[i]] = sreg[i];
-            if (it + 1 < niter) load_stage(it + 1, sreg);
-            const int dyi = it / cb, chunk = it - dyi * cb;
-            const int tap0 = (dy_lo + dyi + 1) * 3;
+                for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int s = (tap0 + dx) * cb + chunk;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const half8 a = as_half8(lds[(s * 2 + ks) * 64 + lane]);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int px = 16 * u + n + dx;    // = 1 + 16u + n + (dx - 1)
-                        const half8 bv = as_half8(stage[px * 8 + ((ks * 4 + kg) ^ (px & 7))]);
-                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv, acc[u], 0, 0, 0);
+                    for (int yp = 0; yp < 2; ++yp) {
+                        float v0 = a[u][2 * yp] + bias, v1 = a[u][2 * yp + 1] + bias;
+                        if (clamp01) {
+                            v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
+                            v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
+                        }
+                        const int64_t oi = (((int64_t)b * p.cout + kg) * p.Ho + 2 * y + yp) * p.Wo + 2 * (x0 + 16 * u + n);
+                        *(float2 *)(out + oi) = make_float2(v0, v1);
+                        if (p.score_target) {
+                            const float2 tg = *(const float2 *)(p.score_target + oi);
+                            const float d0 = v0 - tg.x, d1 = v1 - tg.y;
+                            sq_err += (double)(d0 * d0) + (double)(d1 * d1);
+                        }
                     }
                 }
             }
-        }
+        };
 
-        // lane (n, kg) holds rows 4kg..4kg+3 of pixel n: (co, ypar) = (kg, 0) in registers 0,1 and (kg, 1) in 2,3
-        if (kg < p.cout) {
-            const float bias = p.bias[kg];
+        float4 sreg[5];
+        load_stage(r0, 0, sreg);
+        // One input row.  PH = (r - r0) % 3 makes the accumulator sets compile-time: output row y lives in set
+        // (y - r0 + 1) % 3, so rows r - 1, r, r + 1 are sets PH, PH + 1, PH + 2 (mod 3).
+        auto input_row = [&](auto ph, int r) {
+            constexpr int PH = decltype(ph)::value;
+            constexpr int S_UP = PH % 3, S_MID = (PH + 1) % 3, S_DOWN = (PH + 2) % 3;
+            // which of the three output rows of input row r lie in this segment (wave-uniform)
+            const bool up = r - 1 >= y0 && r - 1 < y1, mid = r >= y0 && r < y1, down = r + 1 >= y0 && r + 1 < y1;
+            for (int chunk = 0; chunk < cb; ++chunk) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+                for (int i = 0; i < 5; ++i)
+                    if (i < 4 || fifth) stage[slot0 + 64 * i] = sreg[i];
+                if (chunk + 1 < cb) load_stage(r, chunk + 1, sreg);
+                else if (r < r1) load_stage(r + 1, 0, sreg);
 #pragma unroll
-                for (int yp = 0; yp < 2; ++yp) {
-                    float v0 = acc[u][2 * yp] + bias, v1 = acc[u][2 * yp + 1] + bias;
-                    if (clamp01) {
-                        v0 = fminf(fmaxf(v0, 0.0f), 1.0f);
-                        v1 = fminf(fmaxf(v1, 0.0f), 1.0f);
-                    }
-                    const int64_t oi = (((int64_t)b * p.cout + kg) * p.Ho + 2 * y + yp) * p.Wo + 2 * (x0 + 16 * u + n);
-                    *(float2 *)(out + oi) = make_float2(v0, v1);
-                    if (p.score_target) {
-                        const float2 tg = *(const float2 *)(p.score_target + oi);
-                        const float d0 = v0 - tg.x, d1 = v1 - tg.y;
-                        sq_err += (double)(d0 * d0) + (double)(d1 * d1);
+                for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        half8 bv[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int px = 16 * u + n + dx;    // = 1 + 16u + n + (dx - 1)
+                            bv[u] = as_half8(stage[px * 8 + ((ks * 4 + kg) ^ (px & 7))]);
+                        }
+                        // output row y = r - dy takes weight tap (dy + 1) * 3 + dx
+                        if (up) {                          // dy = +1
+                            const half8 a = as_half8(lds[(((6 + dx) * cb + chunk) * 2 + ks) * 64 + lane]);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[S_UP][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv[u], acc[S_UP][u], 0, 0, 0);
+                        }
+                        if (mid) {                         // dy = 0
+                            const half8 a = as_half8(lds[(((3 + dx) * cb + chunk) * 2 + ks) * 64 + lane]);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[S_MID][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv[u], acc[S_MID][u], 0, 0, 0);
+                        }
+                        if (down) {                        // dy = -1
+                            const half8 a = as_half8(lds[((dx * cb + chunk) * 2 + ks) * 64 + lane]);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) acc[S_DOWN][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv[u], acc[S_DOWN][u], 0, 0, 0);
+                        }
                     }
                 }
             }
+            // output row r - 1 has all its input rows now; its set becomes that of row r + 2
+            if (up) {
+                store_row(r - 1, acc[S_UP]);
+                acc[S_UP][0] = acc[S_UP][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // the image's last row has no input row below it that would complete it
+            if (r == r1 && mid) store_row(r, acc[S_MID]);
+        };
+        for (int r = r0; r <= r1; r += 3) {
+            input_row(std::integral_constant<int, 0>{}, r);
+            if (r + 1 <= r1) input_row(std::integral_constant<int, 1>{}, r + 1);
+            if (r + 2 <= r1) input_row(std::integral_constant<int, 2>{}, r + 2);
         }
     }
     if (p.score_target) flush_err();
@@ -287,16 +337,17 @@ int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
     }
     if (p.Wb % ROWS_TILE == 0 && p.Hb == p.Hi && p.Wb == p.Wi) {
         const size_t lds_rows = lds + (size_t)ROWS_WAVES * ROWS_STAGE_F4 * sizeof(float4);
-        static bool attr_rows = false;
-        if (!attr_rows) {
+        static bool attr_rows_set[MPC_MAX_DEVICES] = {};
+        if (!attr_rows_set[ctx->device]) {
             MPC_HIP(ctx, hipFuncSetAttribute((const void *)deconv_rgb16_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
-            attr_rows = true;
+            attr_rows_set[ctx->device] = true;
         }
-        const int64_t nt = p.P / ROWS_TILE;
-        int64_t blocks = mpc_cdiv(nt, ROWS_WAVES);
-        if (blocks > NUM_CU) blocks = NUM_CU;          // persistent: one 16-wave workgroup per CU
+        const int seg_rows = strip_rows((int64_t)p.B * (p.Wb / ROWS_TILE), p.Hb);
+        const int64_t nu = (int64_t)p.B * mpc_cdiv(p.Hb, seg_rows) * (p.Wb / ROWS_TILE);
+        int64_t blocks = mpc_cdiv(nu, ROWS_WAVES);
+        if (blocks > NUM_CU) blocks = NUM_CU;      // persistent: one 16-wave workgroup per CU
         blocks = xcd_grid(blocks);
-        deconv_rgb16_rows_kernel<<<dim3((unsigned)blocks), dim3(64 * ROWS_WAVES), lds_rows, ctx->stream>>>(p, (const float4 *)c->wpk_rgb16, nsteps, nt);
+        deconv_rgb16_rows_kernel<<<dim3((unsigned)blocks), dim3(64 * ROWS_WAVES), lds_rows, ctx->stream>>>(p, (const float4 *)c->wpk_rgb16, nsteps, nu, seg_rows);
         MPC_CHECK_LAUNCH(ctx, "deconv_rgb16_rows");
         return MPC_OK;
     }

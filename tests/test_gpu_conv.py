@@ -209,6 +209,23 @@ def test_fp16_last_layer_row_tiled_kernel(dev, ops, hw):
     assert torch.equal(clamped, got.clamp(0, 1))
 
 
+def test_fp16_last_layer_segments_longer_than_the_minimum(dev, ops):
+    """The row-tiled kernel walks column strips in segments of rows sized so that all segments fit one round of
+    its persistent grid: small inputs get the 4-row minimum, this one (128 strips x 170 rows) 6-row segments with
+    a ragged last one.  Checked against the fp32 reference like the small cases."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(170)
+    x = torch.randn(2, 192, 170, 2048, generator=g).half()
+    w, b = _w(g, 192, 3, 5, 5, scale=0.02), _w(g, 3, scale=0.5)
+    layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, f16=True)
+    got = layer(x.to(dev).permute(0, 2, 3, 1).contiguous()).cpu()
+    want = F.conv_transpose2d(x.float(), w.half().float(), b, stride=2, padding=2, output_padding=1)
+    assert got.shape == want.shape
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    print(f"fp16 last layer 170 x 2048: max err / max {err:.2e}")
+    assert err < 1e-5                      # same fp16 operands, fp32 accumulation on both sides
+
+
 def to_split(x_nhwc, scale=256.0):
     """fp32 NHWC -> S16 split tensor [B,H,W,C/8,16] (hi x8 | lo x8), the format f16x3 layers read."""
     v = (x_nhwc * scale).float()
