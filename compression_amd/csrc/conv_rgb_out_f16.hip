@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * RGB16_WAVES, 2) void deconv_rgb16_kernel(const
 constexpr int ROWS_WAVES = 16;
 constexpr int ROWS_TILE = 32;
 constexpr int ROWS_STAGE_F4 = 34 * 8;      // 16-byte slots of one staging tile
-constexpr int STRIP_ROWS_MIN = 4, STRIP_ROWS_MAX = 32;
+constexpr int STRIP_ROWS_MIN = 2, STRIP_ROWS_MAX = 32;
 
 inline int strip_rows(int64_t strips, int Hb) {
     int64_t segs = (int64_t)NUM_CU * ROWS_WAVES / (strips > 0 ? strips : 1);   // segments per strip that fit one round
@@ -196,8 +196,10 @@ __global__ __launch_bounds__(64 * ROWS_WAVES) void deconv_rgb16_rows_kernel(cons
     const int64_t per_xcd = (nunits + NUM_XCD - 1) / NUM_XCD;
     const int64_t t0 = (int64_t)(blockIdx.x % NUM_XCD) * per_xcd;
     const int64_t t1 = (t0 + per_xcd < nunits) ? t0 + per_xcd : nunits;
-    const int64_t stride = (int64_t)(gridDim.x / NUM_XCD) * ROWS_WAVES;
-    for (int64_t t = t0 + (int64_t)(blockIdx.x / NUM_XCD) * ROWS_WAVES + wave; t < t1; t += stride) {
+    // wave w of the XCD's workgroup k takes units w * (workgroups of the XCD) + k, ...: a grid that is not full leaves
+    // waves idle on every CU rather than CUs idle
+    const int64_t wgs = gridDim.x / NUM_XCD, stride = wgs * ROWS_WAVES;
+    for (int64_t t = t0 + (int64_t)wave * wgs + blockIdx.x / NUM_XCD; t < t1; t += stride) {
         // unit t = (image, segment, strip), strips of one segment next to each other
         const int x0 = (int)(t % tw) * ROWS_TILE;
         const int64_t rest = t / tw;
@@ -344,8 +346,7 @@ int mpc_conv_launch_rgb16(mpc_ctx *ctx, const Params &p, const mpc_conv *c) {
         }
         const int seg_rows = strip_rows((int64_t)p.B * (p.Wb / ROWS_TILE), p.Hb);
         const int64_t nu = (int64_t)p.B * mpc_cdiv(p.Hb, seg_rows) * (p.Wb / ROWS_TILE);
-        int64_t blocks = mpc_cdiv(nu, ROWS_WAVES);
-        if (blocks > NUM_CU) blocks = NUM_CU;      // persistent: one 16-wave workgroup per CU
+        int64_t blocks = nu < NUM_CU ? nu : NUM_CU; // persistent: one 16-wave workgroup per CU
         blocks = xcd_grid(blocks);
         deconv_rgb16_rows_kernel<<<dim3((unsigned)blocks), dim3(64 * ROWS_WAVES), lds_rows, ctx->stream>>>(p, (const float4 *)c->wpk_rgb16, nsteps, nu, seg_rows);
         MPC_CHECK_LAUNCH(ctx, "deconv_rgb16_rows");

@@ -211,7 +211,7 @@ def test_fp16_last_layer_row_tiled_kernel(dev, ops, hw):
 
 def test_fp16_last_layer_segments_longer_than_the_minimum(dev, ops):
     """The row-tiled kernel walks column strips in segments of rows sized so that all segments fit one round of
-    its persistent grid: small inputs get the 4-row minimum, this one (128 strips x 170 rows) 6-row segments with
+    its persistent grid: small inputs get the 2-row minimum, this one (128 strips x 170 rows) 6-row segments with
     a ragged last one.  Checked against the fp32 reference like the small cases."""
     from compression_amd import _lib
     g = torch.Generator().manual_seed(170)
