@@ -305,9 +305,11 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
             return job["sym"].view(job["B"], -1), job["idx"].view(job["B"], -1), job["h"], job["w"]
         return self.encode_batch_finish(job)
 
-    def encode_batch_begin(self, input_image, entropy_coding=True):
+    def encode_batch_begin(self, input_image, entropy_coding=True, input_nhwc=None):
         """Enqueues the encoder's kernels on the current stream and returns at once.  -> a job for encode_batch_finish;
-        job["transforms_done"] is an event recorded behind g_a (what a pipelined caller orders other MFMA work after)."""
+        job["transforms_done"] is an event recorded behind g_a (what a pipelined caller orders other MFMA work after).
+        input_nhwc: the image already in the first layer's layout (ops.nchw_to_nhwc(x, 4)), for a caller that made it
+        ahead of time on another stream and has ordered the current stream behind it."""
         self._ensure_tables()
         x = input_image.contiguous()
         B, M = x.shape[0], self.out_channel_M
@@ -318,8 +320,8 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         nbytes_d, status_d = meta[:2 * B].view(torch.int64), meta[2 * B:3 * B]
         geom_d, nclamp_d = meta[3 * B:3 * B + 2], meta[3 * B + 2:3 * B + 3]
         events = {}
-        _, sym4, _ = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1, nclamp_d,
-                                                  events=events)
+        x4 = input_nhwc if input_nhwc is not None else ops.nchw_to_nhwc(x, 4)
+        _, sym4, _ = self.Encoder.forward_symbols(x4, self.min_feat, self._n_targets() - 1, nclamp_d, events=events)
         transforms_done = torch.cuda.Event()
         transforms_done.record()
         if STRESS_OVERLAP_TRANSFORMS:

@@ -21,6 +21,8 @@ time on one stream (src/compression/tests.py:439-460); it has no counterpart of 
 """
 import torch
 
+from . import ops
+
 
 class CodecPipeline:
     def __init__(self, model, device, after_synthesis=None):
@@ -58,9 +60,19 @@ class CodecPipeline:
         batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1; x_hat is complete on the stream
         `result_stream` (the caller's next use must be ordered behind it)."""
         stream = self.streams[self.count & 1]
+        idle = self.streams[(self.count + 1) & 1]                # (its batch's encoder has ended: encode_batch_finish waited)
         self.count += 1
+        # The image goes to the first layer's layout on the idle stream, beside the g_s that `stream` is still running:
+        # enqueued on `stream` the 45 us pass would sit between that g_s and this batch's g_a, on the critical path.
+        idle.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(idle):
+            x4 = ops.nchw_to_nhwc(x.contiguous(), 4)
+            laid_out = torch.cuda.Event()
+            laid_out.record()
+        x4.record_stream(stream)
         with torch.cuda.stream(stream):
-            enc = self.model.encode_batch_begin(x)
+            stream.wait_event(laid_out)
+            enc = self.model.encode_batch_begin(x, input_nhwc=x4)
         done = None
         if self.pending is not None:
             done = self._decode(self.pending, enc["transforms_done"])
