@@ -381,7 +381,6 @@ def run_rank(args):
         xhat, sse = model.decode_batch_finish(job), job["sse"]
         nbytes = float(sum(len(s) for s in streams))
         acc.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
-        acc.all_reduce()
         return xhat
 
     def forward_step():
@@ -391,7 +390,6 @@ def run_rank(args):
         bits = float(out["bpp_feature"]) * B * H * W
         acc.add_batch_device(sse, 3 * H * W, bits=bits, pixels=B * H * W, nbytes=bits / 8, seconds=state["seconds"],
                              side_bits=float(out["bpp_sidestring"]) * B * H * W, reset=True)
-        acc.all_reduce()
         return xhat
 
     # Throughput mode (default for the codec workloads): two batches in flight on two streams, see
@@ -406,7 +404,6 @@ def run_rank(args):
         if a is None:
             a = accs[key] = StatsAccumulator(device=dev)
         a.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
-        a.all_reduce()
         state["acc"] = a
         return xhat
 
@@ -470,8 +467,12 @@ def run_rank(args):
         xhat = keep_last(step(), xhat)
         marks.append(time.perf_counter())                   # (host time when the step's call returned: shows a stalled step)
     xhat = keep_last(drain(), xhat)                                  # ... and ends with all of its K batches decoded
+    # the job's one collective: the statistics vector of the last batch, summed over the ranks (the steps themselves
+    # exchange nothing, so no rank waits for another inside the loop)
+    state.get("acc", acc).all_reduce()
     barrier()
     dt = time.perf_counter() - t0
+    last = state.get("acc", acc).result()                   # (pipelined: the accumulator of the last batch's stream)
     device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the timed region
     ops.PROFILER = None
     timed_dom = prof.summary()[dom]
@@ -502,7 +503,6 @@ def run_rank(args):
     _, sse = ops.clamp_sse_per_image(xhat, target)
     rep = StatsAccumulator(device=dev)
     torch.cuda.synchronize()
-    last = state.get("acc", acc).result()                   # (pipelined: the accumulator of the last batch's stream)
     rep.add_batch_device(sse, 3 * H * W, bits=last["bits"] / world, pixels=B * H * W, nbytes=last["bytes"] / world,
                          seconds=state["seconds"], side_bits=last["side_bits"] / world, msssim=ms, reset=True)
     stats = rep.all_reduce().result()
