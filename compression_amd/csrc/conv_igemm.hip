@@ -357,6 +357,9 @@ __global__ void pack_weights_kernel(const PackDesc d, const float *__restrict__ 
 // fp16 gamma as cout/64 chunks in the weight-chunk layout of the fp16 kernel (chunk kc = 64 input channels of
 // the mix, 4 k-steps): out[kc][(ks*2 + h)*cout + c'][jj] <- gamma_eff[c'][32f + 16s + 8(jj>>2) + 4h + (jj&3)]
 // with f = 2kc + (ks>>1), s = ks&1: the k order of the accumulator registers
+// A second image follows it for the kernel that multiplies with v_mfma_f32_16x16x32_f16 (deconv5s2_patch_f16.hip), where
+// lane group kg = 2s + h holds, of a 32-channel block, channels 16(jj>>2) + 4kg + (jj&3): same slots, the roles of s
+// and jj>>2 exchanged.
 __global__ void pack_gamma_f16_kernel(const float *__restrict__ gamma_eff, int cout, _Float16 *__restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cout * cout) return;
@@ -365,6 +368,8 @@ __global__ void pack_gamma_f16_kernel(const float *__restrict__ gamma_eff, int c
     int hh = sl & 1, ks = sl >> 1;
     int c = 32 * (2 * kc + (ks >> 1)) + 16 * (ks & 1) + 8 * (jj >> 2) + 4 * hh + (jj & 3);
     out[i] = (_Float16)gamma_eff[(int64_t)cp * cout + c];
+    int c16 = 32 * (2 * kc + (ks >> 1)) + 16 * (jj >> 2) + 8 * (ks & 1) + 4 * hh + (jj & 3);
+    out[(int64_t)cout * cout + i] = (_Float16)gamma_eff[(int64_t)cp * cout + c16];
 }
 
 // max |w| as the bit pattern of a non-negative float (monotone under unsigned compare)
@@ -654,7 +659,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         }
         if (f16) {
             void *g16 = nullptr;
-            if ((e = hipMalloc(&g16, sizeof(_Float16) * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma f16)");
+            if ((e = hipMalloc(&g16, sizeof(_Float16) * 2 * d.cout * d.cout)) != hipSuccess) return fail("hipMalloc(gamma f16)");   // (two operand orders)
             pack_gamma_f16_kernel<<<dim3((unsigned)mpc_cdiv((int64_t)d.cout * d.cout, 256)), dim3(256), 0, ctx->stream>>>((const float *)c->gamma, d.cout, (_Float16 *)g16);
             if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { (void)hipFree(g16); return fail("pack gamma"); }
             (void)hipFree(c->gamma);

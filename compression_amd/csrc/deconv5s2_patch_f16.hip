@@ -9,9 +9,12 @@
 // pixels and keeps the 18 x 10 patch around it, 32 input channels at a time, in LDS: the patch is fetched once per
 // channel block in whole 64-byte runs (1.4x the tile's bytes, the halo) and all taps read it with ds_read_b128.
 //
-// K walk: for each 32-channel block, the taps of this workgroup's phase, two per step.  One tap x 32 channels = two
-// k-steps of v_mfma_f32_32x32x16_f16 over the wave's NF output tiles (a wave = 2 tile rows = 32 pixels x all output
-// channels).  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
+// K walk: for each 32-channel block, the taps of this workgroup's phase, two per step.  One tap x 32 channels = one
+// k-step of v_mfma_f32_16x16x32_f16 over the wave's 2 NF x 2 output tiles (a wave = 2 tile rows of 16 pixels x all
+// output channels in tiles of 16; lane (m, kg) = lane & 15, lane >> 4 holds k-values 8 kg .. 8 kg + 7 of row or
+// column m of an operand and rows 4 kg .. 4 kg + 3 of column m of a result).  The 16 x 16 x 32 shape issues the same
+// FLOPs per cycle as 32 x 32 x 16 but the chip, power-limited in this loop, holds a higher clock with it: 5-6 % of
+// the layers.  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
 // streamed by LDS-DMA one step ahead; the next channel block's patch is brought by LDS-DMA into the other patch buffer
 // during the steps of the current block.  No transfer passes through registers, so a step is: a few DMA issues,
 // 2 x (2 + 2 NF) LDS reads, 4 NF MFMAs, one observed wait for the transfers (dma_wait_last), one s_barrier.
@@ -33,6 +36,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 namespace {
@@ -73,6 +77,7 @@ struct Body {
     static constexpr int WCH_F4 = COUT * 4;              // slots of a half chunk (1 tap x 32 channels): [ks 2][h 2][cout]
     static constexpr int WPW = WCH_F4 / 64 / NW;         // 1 KB pieces of a half chunk that each wave brings
     static_assert(WPW * NW * 64 == WCH_F4, "a half chunk must split evenly into 1 KB pieces per wave");
+    static constexpr int NTL = 2 * NF;                   // 16-channel output tiles
     static_assert(NF % 2 == 0, "gamma's half chunks go two per step");
 
     template <int NTAPS>
@@ -83,7 +88,7 @@ struct Body {
         f4 *par = wring + 4 * WCH_F4;                    // bias [COUT], beta [COUT] (beyond what the transposing store reuses)
 
         const int tid = threadIdx.x;
-        const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63, m = lane & 15, kg = lane >> 4, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
         const int tiles_x = (p.Wb + TILE_W - 1) / TILE_W, tiles_y = (p.Hb + TILE_H - 1) / TILE_H;
         const int64_t blk = xcd_block();
@@ -91,8 +96,8 @@ struct Body {
         const int b = (int)(blk / (tiles_y * tiles_x));
         const int trem = (int)(blk - (int64_t)b * tiles_y * tiles_x);
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        const int by = ty * TILE_H + 2 * wave + (j >> 4), bx = tx * TILE_W + (j & 15);
-        const bool pvalid = by < p.Hb && bx < p.Wb;
+        // this lane's two pixels: column m of tile rows 2 wave and 2 wave + 1
+        const int by0 = ty * TILE_H + 2 * wave, bx = tx * TILE_W + m;
 
         // ---- patch staging: slot s of the LDS image <- 16 bytes of the input (or of the zero page) ------------
         const _Float16 *in_b = (const _Float16 *)p.in + (int64_t)b * p.Hi * p.Wi * p.Cs;
@@ -119,7 +124,7 @@ struct Body {
         // ---- weights: half chunks (tap, cb) of the packed image, then gamma's, two per step, by LDS-DMA ------------
         const int ncb = p.Cs / 32;                       // 32-channel blocks
         const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + ph.w_off);
-        const f4 *gsrc = (const f4 *)p.gamma;
+        const f4 *gsrc = (const f4 *)p.gamma + (int64_t)COUT * COUT / 8;   // (the image in this kernel's k order follows the other one)
         // packed order: chunk (tap, 64-channel block) at (tap * ncb/2 + cb/2) full chunks, its halves 12 KB apart
         auto w_half = [&](int tap, int cb) -> const f4 * {
             return wsrc + ((int64_t)(tap * (ncb >> 1) + (cb >> 1)) * 2 + (cb & 1)) * WCH_F4;
@@ -147,35 +152,28 @@ struct Body {
         dma_wait_last(probe(0));
         __syncthreads();
 
-        // the accumulators start from the bias: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h
-        f32x16 acc[NF];
+        // the accumulators start from the bias: acc[t][u][r] = channel 16 t + 4 kg + r of pixel (row u, column m)
+        f32x4 acc[NTL][2];
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4 bb = par[8 * f + 2 * g + h];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[f][4 * g + t] = bb[t];
-            }
+        for (int t = 0; t < NTL; ++t) acc[t][0] = acc[t][1] = par[4 * t + kg];
 
-        // this lane's pixel in the patch (tap (0,0) is patch row + 1, column + 1), piece h of each k-step
-        const int lane_slot = (2 * wave + (j >> 4) + 1) * ROW_F4 + ((j & 15) + 1) * PIX_F4 + h;
+        // the lane's pixel of row 0 in the patch (tap (0,0) is patch row + 1, column + 1), its piece kg of 8 channels
+        const int lane_slot = (2 * wave + 1) * ROW_F4 + (m + 1) * PIX_F4 + kg;
         int wbuf = 0;                                    // weight buffer of the current step
         int pbuf = 0;
 
         auto one_tap = [&](int tap, const f4 *wl) {
             const int2 d = p.tapv[ph.tap_off + tap];     // uniform index: a scalar load from the kernel arguments
             const f4 *bp = patch + pbuf * PATCH2_F4 + lane_slot + d.x * ROW_F4 + d.y * PIX_F4;
-            const half8 b0 = as_half8(bp[0]), b1 = as_half8(bp[2]);
-            half8 a[2][NF];
+            const half8 b0 = as_half8(bp[0]), b1 = as_half8(bp[ROW_F4]);
+            half8 a[NTL];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) a[0][f] = as_half8(wl[f * 32]);
+            for (int t = 0; t < NTL; ++t) a[t] = as_half8(wl[t * 16]);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) a[1][f] = as_half8(wl[2 * COUT + f * 32]);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][f], b0, acc[f], 0, 0, 0);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][f], b1, acc[f], 0, 0, 0);
+            for (int t = 0; t < NTL; ++t) {
+                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b0, acc[t][0], 0, 0, 0);
+                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b1, acc[t][1], 0, 0, 0);
+            }
         };
 
         // one step: taps 2K and 2K + 1 (if the phase has it) of the current 32-channel block
@@ -198,7 +196,7 @@ struct Body {
                 dma_half(n0, wbuf ^ 1, 0, true);
             }
 
-            const f4 *wl = wring + wbuf * 2 * WCH_F4 + h * COUT + j;
+            const f4 *wl = wring + wbuf * 2 * WCH_F4 + kg * COUT + m;   // slot [ks][h][cout] with kg = 2 ks + h
             one_tap(T0, wl);
             if constexpr (T1 < NTAPS) one_tap(T1, wl + WCH_F4);
             dma_wait_last(probe(wbuf ^ 1));              // everything this wave has issued is in LDS before the barrier
@@ -219,29 +217,23 @@ struct Body {
             pbuf ^= 1;
         }
 
-        // ---- epilogue: acc[f][r] = channel 32f + (r&3) + 8(r>>2) + 4h of pixel (by, bx) --------------------
-        const int oy = by * p.my + ph.qy, ox = bx * p.mx + ph.qx;
+        // ---- epilogue: acc[t][u][r] = channel 16 t + 4 kg + r of pixel (by0 + u, bx) ----------------------------
+        const int ox = bx * p.mx + ph.qx;
         if constexpr (EPI == EPI_GDN) {
             const bool inverse = p.act == MPC_ACT_IGDN;
             // norm[c'] = sum_c gamma[c'][c] * y[c]^2 as NF / 2 more steps of two half chunks: half chunk hc holds
-            // gamma[:, 32 hc .. 32 hc + 31] in the weight layout; the B operand is built from the lane's own accumulators,
-            // whose registers 8s..8s+7 of tile hc are the 8 k-values of k-step s (c = 32 hc + 16 s + 8(jj>>2) + 4h +
-            // (jj&3)).  y^2 is scaled by 2^-8 and saturated before the conversion to fp16; the scale is undone on the sum.
-            f32x16 nrm[NF];                               // starts from beta (in the scale of the sum: 2^-8)
+            // gamma[:, 32 hc .. 32 hc + 31] in the weight layout, its k-values in the order in which a lane holds the
+            // squares: k = 8 kg + e is channel 32 hc + 16 (e >> 2) + 4 kg + (e & 3), registers e & 3 of tiles 2 hc and
+            // 2 hc + 1.  y^2 is scaled by 2^-8 and saturated before the conversion to fp16; the scale is undone on the sum.
+            f32x4 nrm[NTL][2];                                         // starts from beta (in the scale of the sum: 2^-8)
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f4 be = par[COUT / 4 + 8 * f + 2 * g + h];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) nrm[f][4 * g + t] = be[t] * SQ_SCALE;
-                }
-            auto square = [&](int hc, int s2) {
+            for (int t = 0; t < NTL; ++t) nrm[t][0] = nrm[t][1] = par[COUT / 4 + 4 * t + kg] * SQ_SCALE;
+            auto square = [&](int hc, int u) {
                 half8 bv;
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    float y = acc[hc][8 * s2 + jj];
-                    bv[jj] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
+                for (int e = 0; e < 8; ++e) {
+                    float y = acc[2 * hc + (e >> 2)][u][e & 3];
+                    bv[e] = (_Float16)fminf(y * y * SQ_SCALE, HALF_MAX);
                 }
                 return bv;
             };
@@ -255,7 +247,7 @@ struct Body {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int hc = 2 * g2 + e;
-                    const f4 *wl = wring + (wbuf * 2 + e) * WCH_F4 + h * COUT + j;
+                    const f4 *wl = wring + (wbuf * 2 + e) * WCH_F4 + kg * COUT + m;
                     // the next half chunk's operands are squared and converted while this one's MFMAs run
                     half8 bn0 = bv0, bn1 = bv1;
                     if (hc + 1 < NF) {
@@ -263,11 +255,11 @@ struct Body {
                         bn1 = square(hc + 1, 1);
                     }
 #pragma unroll
-                    for (int fo = 0; fo < NF; ++fo)
-                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[fo * 32]), bv0, nrm[fo], 0, 0, 0);
-#pragma unroll
-                    for (int fo = 0; fo < NF; ++fo)
-                        nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(wl[2 * COUT + fo * 32]), bv1, nrm[fo], 0, 0, 0);
+                    for (int t = 0; t < NTL; ++t) {
+                        const half8 aa = as_half8(wl[t * 16]);
+                        nrm[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, bv0, nrm[t][0], 0, 0, 0);
+                        nrm[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aa, bv1, nrm[t][1], 0, 0, 0);
+                    }
                     bv0 = bn0;
                     bv1 = bn1;
                 }
@@ -278,41 +270,48 @@ struct Body {
             }
             __syncthreads();                              // (every transfer was fenced above: the LDS can be reused)
             // y * (beta + norm)^(-1/2) (or ^(+1/2)) through the wave-private transposing store (2 bytes per element:
-            // all output channels in one round); v_rsq_f32 is far more accurate than the fp16 output
+            // all output channels in one round); v_rsq_f32 is far more accurate than the fp16 output.  Row 16 u + m of
+            // the store is pixel (by0 + u, bx); the lanes kg = 0, 1 enter the output index of rows m and 16 + m.
             TransStore ts;
-            ts.init((char *)lds, wave, lane, j, h, pvalid ? (long long)(((int64_t)b * p.Ho + oy) * p.Wo + ox) : -1ll);
+            {
+                const int u = kg & 1, by = by0 + u;
+                const bool pvalid = by < p.Hb && bx < p.Wb;
+                ts.init((char *)lds, wave, lane, 16 * u + m, kg >> 1,
+                        pvalid ? (long long)(((int64_t)b * p.Ho + by * p.my + ph.qy) * p.Wo + ox) : -1ll);
+            }
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int t = 0; t < NTL; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int u = 0; u < 2; ++u) {
                     half4 o;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float a = nrm[f][4 * g + t] * SQ_UNSCALE;
+                    for (int r = 0; r < 4; ++r) {
+                        float a = nrm[t][u][r] * SQ_UNSCALE;
                         float rs = __builtin_amdgcn_rsqf(a);
-                        float y = acc[f][4 * g + t];
-                        o[t] = sat_half(inverse ? y * (a * rs) : y * rs);
+                        float y = acc[t][u][r];
+                        o[r] = sat_half(inverse ? y * (a * rs) : y * rs);
                     }
-                    *(half4 *)ts.at(j, f * 64 + (8 * g + 4 * h) * 2) = o;
+                    *(half4 *)ts.at(16 * u + m, (16 * t + 4 * kg) * 2) = o;
                 }
             ts.template flush<NF * 4>((char *)p.out, (long long)COUT * 2, 0);
         } else {
-            if (!pvalid) return;                          // (every step has waited for its own transfers)
-            _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + oy) * p.Wo + ox) * COUT;
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int u = 0; u < 2; ++u) {                 // (every step has waited for its own transfers)
+                const int by = by0 + u;
+                if (by >= p.Hb || bx >= p.Wb) continue;
+                _Float16 *orow = (_Float16 *)p.out + (((int64_t)b * p.Ho + by * p.my + ph.qy) * p.Wo + ox) * COUT;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int c0 = 32 * f + 8 * g + 4 * h;
+                for (int t = 0; t < NTL; ++t) {
                     half4 o;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float v = acc[f][4 * g + t];
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[t][u][r];
                         if (p.act == MPC_ACT_RELU) v = fmaxf(v, 0.0f);
-                        o[t] = sat_half(v);
+                        o[r] = sat_half(v);
                     }
-                    *(half4 *)(orow + c0) = o;
+                    *(half4 *)(orow + 16 * t + 4 * kg) = o;
                 }
+            }
         }
     }
 };
