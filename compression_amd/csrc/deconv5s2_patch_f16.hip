@@ -17,7 +17,7 @@
 // the layers.  The weights are the packed chunks of conv_igemm_f16.hip read in halves (12 KB for 192 output channels),
 // streamed by LDS-DMA one step ahead; the next channel block's patch is brought by LDS-DMA into the other patch buffer
 // during the steps of the current block.  No transfer passes through registers, so a step is: a few DMA issues,
-// 2 x (2 + 2 NF) LDS reads, 4 NF MFMAs, one observed wait for the transfers (dma_wait_last), one s_barrier.
+// 2 x (2 + 2 NF) LDS reads, 8 NF MFMAs, one observed wait for the transfers (dma_wait_last), one s_barrier.
 //
 // LDS image of a patch (16-byte slots): [row 10][96 slots], pixel c of a row at slots 5c .. 5c+3 (4 x 8 channels) with
 // one slot of padding per pixel and six per row: a pixel pitch of 80 bytes spreads the 16 pixels of a tile row over
@@ -54,7 +54,7 @@ constexpr int PPW = 4;                               // patch pieces (1 KB of DM
 __device__ __forceinline__ half8 as_half8(const f4 &v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ _Float16 sat_half(float v) { return (_Float16)fminf(fmaxf(v, -HALF_MAX), HALF_MAX); }
 
-// A step multiplies TWO taps of the 32-channel block (4 NF MFMAs per wave) between one completion fence + barrier and
+// A step multiplies TWO taps of the 32-channel block (8 NF MFMAs per wave) between one completion fence + barrier and
 // the next: with one tap per step the fence, the barrier's skew and the address arithmetic of a step were paid twice
 // as often (4 % of the layers).  The weights of a step (two half chunks, 24 KB for 192 output channels) are
 // double-buffered: the pair of step s + 1 is issued at the top of step s into the buffer that step s - 1 read.  The
