@@ -26,9 +26,10 @@
 // 64 consecutive slots whatever they hold.
 //
 // Two workgroups of four waves per CU (80 KB of LDS each): their barriers and epilogues fall out of phase, so one's
-// MFMAs cover the other's waits and stores.  Same operand formats, GDN continuation and output path as
-// conv_igemm_f16.hip; the K axis is summed in another order (channel block major), so results agree with it to fp32
-// rounding, not bit for bit.
+// MFMAs cover the other's waits and stores.  Same weight format, GDN continuation and output path as
+// conv_igemm_f16.hip (gamma comes in this kernel's own k order, the second image that pack_gamma_f16_kernel writes);
+// the K axis is summed in another order (channel block major), so results agree with it to fp32 rounding, not bit for
+// bit.
 #include <type_traits>
 
 #include "conv_common.h"
