@@ -53,5 +53,7 @@ else:
         if r is not None:
             pipe.synchronize()
             check(r[3], r[0], r[1])
+        if it % 1000 == 999:
+            print("step", it + 1, "differing so far:", bad, flush=True)   # (a long run must not look hung)
     r = pipe.flush(); pipe.synchronize(); check(r[3], r[0], r[1])
 print("steps that differ:", bad, "of", N, flush=True)
