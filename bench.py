@@ -27,7 +27,7 @@ Extra objects on the JSON line: "roofline" for the dominant kernel (achieved = a
 time by HIP events round each of its launches INSIDE the timed region, on the stream it runs on; the kernel is picked
 in the warm-up, where every launch carries events; traffic = bytes per launch from the committed counter passes, null
 if they were taken on other kernel sources), "kernels" (per-launch averages of all kernels: the dominant one from the
-timed region, the others from the same number of steps run after it one batch at a time with events round every
+timed region, the others from up to 20 steps run after it one batch at a time with events round every
 launch -- ~40 events a step inside the timed region cost 0.6 ms of it and more, growing with the number of steps),
 "cdf_build" (the materialised per-symbol CDF rows at the workload's size, which the fused coder never needs),
 "hbm_ceiling" (device copy / fill rates measured in this run), "cpu_baseline" (the CPU oracle timed on this host),
