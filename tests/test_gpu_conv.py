@@ -190,6 +190,24 @@ def test_fp16_layers_against_fp32_reference(dev, ops, cin, act):
     assert err < 4e-3
 
 
+def test_fp16_transposed_layer_with_128_channels(dev, ops):
+    """The narrow variant (128 channels: 8 accumulator tiles of 16 channels per wave) of the fp16 transposed layer with
+    IGDN, on a grid that is not a multiple of the 16 x 8 tile."""
+    from compression_amd import _lib
+    g = torch.Generator().manual_seed(128)
+    x = torch.randn(2, 128, 11, 19, generator=g)
+    w, b = _w(g, 128, 128, 5, 5), _w(g, 128)
+    beta = 1.0 + torch.rand(128, generator=g)
+    gamma = 0.3 * torch.rand(128, 128, generator=g) * (torch.arange(128).view(-1, 1) / 128.0 + 0.1)
+    want = O.gdn(F.conv_transpose2d(x, w, b, stride=2, padding=2, output_padding=1), beta, gamma, inverse=True)
+    layer = ops.ConvLayer(_lib.MPC_DECONV, w.to(dev), b.to(dev), 5, 2, _lib.MPC_ACT_IGDN, beta.to(dev), gamma.to(dev), f16=True)
+    got = layer(nhwc(x).to(dev).half()).float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    err = rel_err(got, want)
+    print(f"fp16 transposed layer, 128 channels: rel err {err:.2e}")
+    assert err < 4e-3
+
+
 @pytest.mark.parametrize("hw", [(5, 64), (3, 32), (1, 96)])
 def test_fp16_last_layer_row_tiled_kernel(dev, ops, hw):
     """The fp16 192 -> 3 layer on inputs whose width is a multiple of 32 takes the row-tiled kernel (horizontal
