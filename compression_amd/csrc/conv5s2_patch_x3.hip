@@ -87,13 +87,18 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 
     // ---- weights: chunk (tap, cb) of the packed image, through a ring of three chunks in LDS ----------------------
     // In the K loop a chunk travels global -> registers -> LDS: chunk c + 2 is loaded at the top of tap c and written
-    // to the ring at the end of tap c + 1, so it has two taps to arrive and the only waits are the compiler's counted
-    // ones on its registers.  LDS-DMA is not used there: a counted s_waitcnt does not tell that its pieces are in LDS
-    // (one wrong launch in 500 of the largest layer), and the full wait (vmcnt(0), then dma_wait_last) also waits for the
-    // patch loads of the next block, which are meant to stay in flight for many taps (that wait cost 6 % of the layer).
-    // The GDN steps have no other load in flight and keep LDS-DMA with an observed wait per step.
+    // to the ring early in tap c + 1 (behind the MFMAs of its second output tile), so it has a tap and more to arrive,
+    // the only waits on the loads are the compiler's counted ones on its registers, and the write is complete in LDS
+    // long before the tap's barrier waits for it (barrier_after_lds_writes: a wave may not arrive at the barrier
+    // with the write still queued -- the next tap reads the chunk).  LDS-DMA is not used there: the wait for its
+    // pieces (vmcnt(0), then dma_wait_last) also waits for the patch loads of the next block, which are meant to stay
+    // in flight for many taps (that wait cost 6 % of the layer).  The GDN steps have no other load in flight and keep
+    // LDS-DMA with an observed wait per step.
 #ifndef MPC_X3_STAGED_W
 #define MPC_X3_STAGED_W 1
+#endif
+#ifndef MPC_X3_W_AT
+#define MPC_X3_W_AT 1                                     // output tile after whose MFMAs a tap writes the ring
 #endif
     const int ncb = p.Cs / 16;                            // 16-channel blocks
     const f4 *wsrc = (const f4 *)((const _Float16 *)p.wpk + (int64_t)blockIdx.z * p.w_group);
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
-            if (q == WPW - 1) dma_mark_last(wring + slot * WCH_F4 + piece * 64 + lane);   // the piece whose arrival is observed
+            if (q == 0) dma_mark(wring + slot * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // the last piece's arrival is observed:
+            if (q == WPW - 1) dma_marks_stored();                                               // its marks are in LDS before it goes out
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
@@ -160,10 +166,9 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
+            if (f == MPC_X3_W_AT) { MPC_X3_W_END() }        /* early in the tap: the write completes under the MFMAs */ \
         }                                                                                                              \
-        MPC_X3_W_END()                                                                                                 \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        asm volatile("" ::: "memory");                                                                                 \
+        barrier_after_lds_writes();                         /* the chunk just written is read in the next tap */        \
         slot = slot == 2 ? 0 : slot + 1;                                                                               \
     }
 #if MPC_X3_STAGED_W
@@ -188,8 +193,7 @@ __global__ __launch_bounds__(32 * TR, 2) void conv5s2_patch_x3_kernel(const Para
         MPC_PATCH_TAP(20) MPC_PATCH_TAP(21) MPC_PATCH_TAP(22) MPC_PATCH_TAP(23) MPC_PATCH_TAP(24)
         if (more) {                                       // every wave has read the old patch (barrier above)
             write_patch();                                // (the staged registers' wait also retires the DMA issued before them)
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            barrier_after_lds_writes();
         }
     }
 #undef MPC_PATCH_TAP
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
-            if (q == WPW - 1) dma_mark_last(wring + slot * WCH_F4 + piece * 64 + lane);   // the piece whose arrival is observed
+            if (q == 0) dma_mark(wring + slot * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // the last piece's arrival is observed:
+            if (q == WPW - 1) dma_marks_stored();                                               // its marks are in LDS before it goes out
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }

@@ -23,41 +23,34 @@ inline int64_t xcd_grid(int64_t blocks) { return (blocks + NUM_XCD - 1) / NUM_XC
 #define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 #if defined(__HIPCC__)
 // Completion of LDS-DMA transfers (global_load_lds), observed in the data.
-// vmcnt does not tell when an LDS-DMA transfer is in LDS: the counter drops when the data has come back from memory, and
-// the write into LDS can still be on its way, so another wave that passes the barrier can read the old contents.  Seen
-// as single wrong tiles, a few per thousand launches, once other kernels shared the CUs; delays in front of the barrier
-// (s_sleep, a read-back) made the errors rarer, not impossible.  So the arrival is observed.  A wave's transfers are
-// written in the order they were issued, so the LAST piece (64 lanes x 16 bytes) of a batch is watched: before that
-// piece is issued every lane marks the first and the last dword of its own 16 destination bytes with a value no operand
-// holds (two fp16 NaNs with every bit set: weights, gamma and activations are finite) and waits for those stores; the
-// wait for the batch is vmcnt(0) and then a poll of the marked dwords until no lane sees the mark.
-// What this does NOT cover: with a workgroup of ANOTHER transform kernel on the same CU (the last analysis layer run
-// beside the transposed layers) that other kernel's LDS was still hit, 4-11 times in 2 500 steps, and never with the
-// DMA-free kernel in the transposed layers' place.  CodecPipeline therefore never runs two transforms side by side;
-// beside the entropy coders' kernels 20 000 steps of 24 images were bit-identical.
-//   issue all pieces but the last;  dma_mark_last(lane's destination of the last piece);  issue it;  ...
+// A wave's vmcnt drops when the data of an LDS-DMA transfer has come back from memory; the write into LDS is then queued,
+// not necessarily performed, and nothing the issuing wave can wait on counts it.  A wave that leaves the following
+// s_barrier first can therefore read the old bytes of the destination (seen as single wrong tiles, a few per thousand
+// launches, once other kernels kept the CU's LDS busy; delays in front of the barrier only made them rarer).  So the
+// arrival is observed.  A wave's transfers are written in the order they were issued, so the LAST piece (64 lanes x 16
+// bytes) of a batch is watched: every lane marks the first and the last dword of its own 16 destination bytes with a
+// value no operand holds (two fp16 NaNs with every bit set: weights, gamma and activations are finite), the marks are
+// complete in LDS (lgkmcnt(0)) before that piece is issued, and the wait for the batch is vmcnt(0) followed by a poll
+// of the marked dwords until no lane sees the mark.  The marks can be stored well ahead of the piece (dma_mark at the
+// top of a step, the other pieces in between, dma_marks_stored right in front of the watched piece), so that their
+// latency is covered by the issue of the other pieces.
+//   dma_mark(lane's destination of the last piece);  issue all pieces but the last;  dma_marks_stored();  issue it;  ...
 //   dma_wait_last(the same address);  barrier
 constexpr unsigned DMA_MARK = 0xFFFFFFFFu;
 typedef __attribute__((address_space(3))) volatile unsigned *lds_u32_ptr;
 
-// Two forms of the wait, chosen at build time (-DMPC_DMA_OBSERVE=1 | 0):
-//   1  the observed arrival described above: costs 11 % of the transposed layers (the marks must be in LDS before the
-//      last piece goes out);
-//   0  (default) vmcnt(0), a read of the watched piece's first dword by the issuing wave, 64 cycles of sleep: not a
-//      proof, but with it 20 000 pipelined steps were bit-identical as well, and it is 2.7 % of a codec step faster.
-#ifndef MPC_DMA_OBSERVE
-#define MPC_DMA_OBSERVE 0
-#endif
-__device__ __forceinline__ void dma_mark_last(void *lane_dst) {
-#if !MPC_DMA_OBSERVE
-    (void)lane_dst;
-    return;
-#endif
+__device__ __forceinline__ void dma_mark(void *lane_dst) {
     lds_u32_ptr q = (lds_u32_ptr)(__attribute__((address_space(3))) void *)lane_dst;
     q[0] = DMA_MARK;
     q[3] = DMA_MARK;
+}
+__device__ __forceinline__ void dma_marks_stored() {
     __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));              // lgkmcnt(0): the marks are in LDS
     asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void dma_mark_last(void *lane_dst) {
+    dma_mark(lane_dst);
+    dma_marks_stored();
 }
 
 __device__ __forceinline__ void dma_wait_last(void *lane_dst) {
@@ -65,17 +58,6 @@ __device__ __forceinline__ void dma_wait_last(void *lane_dst) {
     asm volatile("" ::: "memory");
 #ifdef MPC_NO_DMA_FENCE                                    // (measurement builds only: what the wait costs beyond vmcnt(0))
     return;
-#endif
-#if !MPC_DMA_OBSERVE
-    {
-        unsigned probe;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                     : "=v"(probe)
-                     : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lane_dst)
-                     : "memory");
-        __builtin_amdgcn_s_sleep(1);
-        return;
-    }
 #endif
     // The poll, as one opaque block (a loop in the source makes the register allocator spill the accumulators that are
     // live across it): read the two marked dwords, leave when no lane sees the mark.  Bounded: a kernel must end even
@@ -100,6 +82,19 @@ __device__ __forceinline__ void dma_wait_last(void *lane_dst) {
         : "=&v"(first), "=&v"(last), "=&s"(seen), "+s"(tries)
         : "v"(addr)
         : "vcc", "scc", "memory");
+}
+
+// Workgroup barrier behind LDS writes that other waves read after it.  A raw s_barrier does not wait for the wave's own
+// LDS instructions: the hardware lets a wave arrive at the barrier with ds_write (and ds_read) still queued, so a wave
+// that leaves the barrier first can read the old bytes.  lgkmcnt(0) is the completion of this wave's LDS writes; with it
+// in front of the barrier every write issued before it is in LDS when any wave passes (what __syncthreads() emits, without
+// its vmcnt(0), which would also drain the global loads that are meant to stay in flight across the barrier).
+__device__ __forceinline__ void barrier_after_lds_writes() {
+#ifndef MPC_EXPERIMENT_NO_LDS_WRITE_WAIT
+    __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));              // lgkmcnt(0)
+#endif
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 // vmcnt(0) only: for waves that have issued nothing that needs watching

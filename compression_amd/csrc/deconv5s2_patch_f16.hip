@@ -131,19 +131,22 @@ struct Body {
             return wsrc + ((int64_t)(tap * (ncb >> 1) + (cb >> 1)) * 2 + (cb & 1)) * WCH_F4;
         };
         // A batch of transfers is issued patch pieces first, then the second half chunk, then the first, whose last
-        // piece is the one whose arrival is observed (dma_mark_last / dma_wait_last): `watched`.
+        // piece is the one whose arrival is observed (`watched`): its destination is marked (dma_mark) before the batch's
+        // first piece goes out, so the marks reach LDS while the other pieces are issued, and the wait for them
+        // (dma_marks_stored) in front of the watched piece finds them there.
         auto probe = [&](int buf) { return wring + buf * 2 * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane; };
         auto dma_half = [&](const f4 *src, int buf, int half, bool watched = false) {
 #pragma unroll
             for (int q = 0; q < WPW; ++q) {
                 const int piece = wave * WPW + q;
-                if (watched && q == WPW - 1) dma_mark_last(probe(buf));
+                if (watched && q == WPW - 1) dma_marks_stored();
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
                                                  (__attribute__((address_space(3))) void *)(wring + (buf * 2 + half) * WCH_F4 + piece * 64), 16, 0, 0);
             }
         };
 
         // prologue: weights of step 0, patch of block 0; bias and beta go to LDS, where the epilogue finds them
+        dma_mark(probe(0));
 #pragma unroll
         for (int i = 0; i < PPW; ++i) dma_patch(i, 0, 0);
         dma_half(w_half(1, 0), 0, 1);
@@ -182,6 +185,7 @@ struct Body {
             constexpr int K = decltype(k_c)::value, T0 = 2 * K, T1 = 2 * K + 1;
             // the next block's patch (the last block fetches its own again, into the buffer nobody reads)
             constexpr int first = K * ((PPW + NSTEPS - 1) / NSTEPS);
+            dma_mark(probe(wbuf ^ 1));                   // (every wave has passed the barrier behind that buffer's last read)
 #pragma unroll
             for (int i = 0; i < pieces_in_step2<NSTEPS>(K); ++i) dma_patch(first + i, more ? cb + 1 : cb, pbuf ^ 1);
             // the next step's weights: in this block, in the next block, or gamma's first two half chunks
@@ -242,6 +246,7 @@ struct Body {
 #pragma unroll
             for (int g2 = 0; g2 < NF / 2; ++g2) {
                 if (g2 + 1 < NF / 2) {
+                    dma_mark(probe(wbuf ^ 1));
                     dma_half(gsrc + (int64_t)(2 * g2 + 3) * WCH_F4, wbuf ^ 1, 1);
                     dma_half(gsrc + (int64_t)(2 * g2 + 2) * WCH_F4, wbuf ^ 1, 0, true);
                 }

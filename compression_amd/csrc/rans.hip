@@ -363,7 +363,10 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
 // ---------------------------------------------------------------------------------------------
 constexpr int RING = 8;                    // LDS row slots per workgroup (power of two, >= AHEAD + 2)
 constexpr int INFLIGHT = 3;                // rows whose DMA may still be in flight behind the newest issued one
-constexpr int AHEAD = INFLIGHT + 1;        // barriers the loader runs ahead of the decoder
+constexpr int AHEAD = INFLIGHT + 2;        // barriers the loader runs ahead of the decoder: one more than its counted wait
+                                           // needs (vmcnt tells that a row's data has come back, not that the write into
+                                           // LDS has been performed), so every row is read at least one whole step after
+                                           // the wait that retired it
 constexpr int DMA_PITCH = 264;             // row pitch (entries) of the aligned table copy: 528 bytes
 static_assert(NOALLOC_SCRATCH_BYTES == (size_t)NOALLOC_MAX_ROWS * DMA_PITCH * sizeof(uint16_t), "static scratch size");
 constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
@@ -376,7 +379,7 @@ template <int K>
 __device__ __forceinline__ void drain_rows() {
     MPC_WAIT_VMCNT(2 * (K > 0 ? K : 0));
     __builtin_amdgcn_s_barrier();
-    if constexpr (K > -1) drain_rows<K - 1>();
+    if constexpr (K > INFLIGHT - AHEAD) drain_rows<K - 1>();      // K = INFLIGHT - 1 .. INFLIGHT - AHEAD: AHEAD barriers
 }
 
 __global__ void align_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, int L, uint16_t *__restrict__ out) {
@@ -392,11 +395,12 @@ __global__ void align_rows_kernel(const uint16_t *__restrict__ table, int64_t ro
 // hardware keeps DS instructions and LDS-DMA loads in order (a ds_read issued after a DMA waits for it to
 // land), so a wave that both loads and searches serialises on every row; the loader therefore executes no DS
 // instruction in its loop, and the two waves meet at one raw s_barrier per symbol:
-//   loader, iteration i : issue row i (slot i % RING); wait until rows <= i - INFLIGHT have landed; barrier #i
+//   loader, iteration i : issue row i (slot i % RING); wait until rows <= i - INFLIGHT have come back; barrier #i
 //   decoder, step n     : barrier #(n + AHEAD); search row n, read the segment heads of row n + 1
-// Barrier #(n + AHEAD) follows the loader's wait for row n + 1.  The loader overwrites the slot of row
-// i - RING only after barrier #(i - 1), which the decoder passed before step i - 1 - AHEAD, when every read up
-// to row i - AHEAD - 1 >= i - RING + 1 had been issued and consumed.  Both waves execute nmax + AHEAD barriers.
+// Barrier #(n + AHEAD) follows the loader's wait for row n + 2: the rows read in step n were retired at least one
+// barrier (one whole step of the coder's chain) earlier.  The loader overwrites the slot of row i - RING only after
+// barrier #(i - 1), which the decoder passes at the top of step i - 1 - AHEAD, when the newest row it can still be
+// reading is row i - 1 - AHEAD > i - RING.  Both waves execute nmax + AHEAD barriers.
 //
 // The decoder's serial chain per symbol is: ballot over the 16 segment heads (in registers, read a step
 // ahead) -> read the segment's 16 entries -> ballot -> read (start, end) -> new state.  The next
@@ -548,14 +552,14 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
     const uint16_t *rbase = &ring[0][gw][0];               // this group's row in slot 0
 
 #pragma unroll
-    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): row 0 has landed
+    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): rows 0 and 1 have landed
     asm volatile("" ::: "memory");
     uint32_t heads = rbase[16 * t];                        // segment heads of row 0
     uint32_t wnext = wr[wpos & (WRING - 1)];
     uint32_t xslot = x & 0xffffu;
     uint32_t mysym = 0;
     for (uint32_t n = 0; n < nmax; ++n) {
-        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows n and n + 1 have landed
+        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows up to n + 2 have landed
         asm volatile("" ::: "memory");
         const uint16_t *row = rbase + (n & (RING - 1)) * (4 * 256);
         const uint32_t heads_nx = rbase[((n + 1) & (RING - 1)) * (4 * 256) + 16 * t];   // off the chain

@@ -78,7 +78,7 @@ def test_4k_image_round_trip(dev):
 def test_two_batches_in_flight_repeat_the_same_bits(dev):
     """The benchmark's step with two batches in flight (CodecPipeline), 120 times on one batch: every result equals
     the one-batch-at-a-time result, byte strings and reconstruction.  This is the regression test of the LDS-DMA
-    completion fence: with the transforms' LDS-DMA transfers only waited for by vmcnt(0), 6 % of such steps had one
+    completion wait: with the transforms' LDS-DMA transfers only waited for by vmcnt(0), 6 % of such steps had one
     wrong tile in a transposed layer once the coders of the other batch shared the CUs."""
     from compression_amd.pipeline import CodecPipeline
     m = _model(dev, analysis_precision="f16x3", synthesis_precision="fp16")
@@ -99,4 +99,39 @@ def test_two_batches_in_flight_repeat_the_same_bits(dev):
         if r is not None:
             check(r)
     check(pipe.flush())
+    assert not bad, f"steps {bad} differ from the one-batch-at-a-time result"
+
+
+def test_transforms_side_by_side_give_the_same_bits(dev):
+    """g_s of one batch started behind the THIRD layer of the next batch's g_a, so that the transposed layers share the
+    CUs with the last analysis layer (CodecPipeline never does that: it is slower), 600 steps: every result equals the
+    one-batch-at-a-time result.  Regression test of the patch kernels' barriers: when a wave could arrive at the tap's
+    s_barrier with its ds_write of the next weight chunk still queued (no lgkmcnt(0) in front of the barrier), the
+    waves that left the barrier first read the old chunk, and 3 of 1 000 such steps had a few wrong symbols in one
+    wave's 32 pixels of the last analysis layer -- only in this placement, where the other kernel keeps the CU's LDS
+    busy."""
+    from compression_amd import manynets_compressor
+    from compression_amd.pipeline import CodecPipeline
+    m = _model(dev, analysis_precision="f16x3", synthesis_precision="fp16")
+    x = synth.rand_image(1000, 24, 512, 768).to(dev)
+    strings, idx, h, w = m.encode_batch(x)
+    recon = m.decode_batch(strings, idx, h, w).clone()
+    torch.cuda.synchronize()
+    bad = []
+    manynets_compressor.STRESS_OVERLAP_TRANSFORMS = True
+    try:
+        pipe = CodecPipeline(m, dev)
+
+        def check(r):
+            pipe.synchronize()
+            if r[0] != strings or not torch.equal(r[1], recon):
+                bad.append(r[3])
+
+        for it in range(600):
+            r = pipe.submit(x, tag=it)
+            if r is not None:
+                check(r)
+        check(pipe.flush())
+    finally:
+        manynets_compressor.STRESS_OVERLAP_TRANSFORMS = False
     assert not bad, f"steps {bad} differ from the one-batch-at-a-time result"
