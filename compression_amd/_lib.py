@@ -5,9 +5,11 @@ operations raise -- there is no CPU or PyTorch fallback.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
 import subprocess
+import weakref
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -116,7 +118,35 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        atexit.register(shutdown)             # registered after torch's own hooks, so it runs before them
     return _lib
+
+
+# Objects that own device memory through a library handle (Context, ops' layer objects).  They are closed from an
+# atexit hook, i.e. while the interpreter, torch and the HIP runtime are all still up: a __del__ that runs during
+# interpreter finalisation would call hipFree after other libraries' exit handlers (a profiler's tool library, the
+# runtime's own teardown) may already have run, which ended a profiled run with a segmentation fault inside exit().
+_owners = weakref.WeakSet()
+_shut_down = False
+
+
+def register_owner(obj):
+    """obj.close() is called at interpreter exit if obj is still alive then."""
+    _owners.add(obj)
+
+
+def shutdown():
+    """Frees every live handle now; later close() / __del__ calls find nothing left to free.  Idempotent."""
+    global _shut_down
+    if _shut_down:
+        return
+    _shut_down = True
+    for obj in list(_owners):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    _contexts.clear()
 
 
 def ptr(t):
@@ -135,6 +165,7 @@ class Context:
             raise MpcError(f"mpc_create(device {device_index}) failed with {rc}: no usable MI355X / HIP runtime")
         self.handle = h
         self.device_index = device_index
+        register_owner(self)
 
     def set_stream(self, stream_handle: int):
         self.check(self.lib.mpc_set_stream(self.handle, c_void_p(stream_handle)))
@@ -147,11 +178,14 @@ class Context:
     def call(self, name: str, *args):
         self.check(getattr(self.lib, name)(self.handle, *args))
 
+    def close(self):
+        if getattr(self, "handle", None):
+            handle, self.handle = self.handle, None
+            self.lib.mpc_destroy(handle)
+
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self.lib.mpc_destroy(self.handle)
-                self.handle = None
+            self.close()
         except Exception:
             pass
 

@@ -602,6 +602,7 @@ class ConvLayer:
         ctx.check(ctx.lib.mpc_conv_create(ctx.handle, ctypes.byref(self.desc), ptr(w), ptr(b), ptr(be), ptr(ga), ctypes.byref(h)))
         self.handle = h
         self._lib = ctx.lib
+        _lib.register_owner(self)
 
     def out_hw(self, H: int, W: int) -> Tuple[int, int]:
         ho, wo = ctypes.c_int(), ctypes.c_int()
@@ -712,10 +713,13 @@ class ConvLayer:
             fl += 2.0 * B * Ho * Wo * self.cout * self.cout
         return fl
 
+    def close(self):
+        if getattr(self, "handle", None):
+            handle, self.handle = self.handle, None
+            self._lib.mpc_conv_destroy(handle)
+
     def __del__(self):
         try:
-            if getattr(self, "handle", None):
-                self._lib.mpc_conv_destroy(self.handle)
-                self.handle = None
+            self.close()
         except Exception:
             pass
