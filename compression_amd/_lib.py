@@ -49,6 +49,7 @@ SIGNATURES = {
     "mpc_symbols_to_latent_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "mpc_download_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t]),
     "mpc_sum_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpc_gdn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p]),
     "mpc_clamp_sse": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mpc_clamp_sse_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "mpc_stats_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, POINTER(c_double), c_int, c_void_p]),

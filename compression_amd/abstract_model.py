@@ -65,6 +65,7 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         self.num_distributions = 1
         self.passthrough_ae = passthrough_ae
         self._synthesis_precision = kwargs.get("synthesis_precision", None)
+        self.table_authority = kwargs.get("table_authority", "device")     # see update_entropy_table
 
     # ---- helpers ---------------------------------------------------------------------------
     def _require_eval(self):
@@ -105,10 +106,18 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
             "bpp": bpp_feature + bpp_z,
         }
 
-    def update_entropy_table(self):
-        """int16 CDF table of the factorised z prior, in-repo rounding order (abstract_model.py:274-291)."""
+    def update_entropy_table(self, authority=None):
+        """int16 CDF table of the factorised z prior, in-repo rounding order (abstract_model.py:274-291).
+        authority "device" (default) | "host": who evaluates the float table, as in the Manypriors model's method."""
+        authority = authority or self.table_authority
+        if authority not in ("device", "host"):
+            raise ValueError(f"table authority must be 'device' or 'host', got {authority!r}")
         L = self._n_targets()
-        tf = self.bitEstimator_z.table(self.min_feat - 0.5, L)                 # [N, L]
+        if authority == "host":
+            dev = next(self.bitEstimator_z.parameters()).device
+            tf = self.bitEstimator_z.table_host(self.min_feat - 0.5, self.max_feat + 0.5, L).to(dev)
+        else:
+            tf = self.bitEstimator_z.table(self.min_feat - 0.5, L)             # [N, L]
         self.main_targets_first, self.main_targets_n = self.min_feat_gaussian - 0.5, \
             int((-self.min_feat_gaussian + self.max_feat_gaussian) / self.q_intv + 2)
         self.z_entropy_table_float = self.entropy_table_float = tf

@@ -4,6 +4,7 @@ The modules own the Bitparm parameters (same names/shapes as the reference) and 
 chain through libmpc (`mpc_bitparm_cdf_eval` / `mpc_bitparm_cdf_table`).
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -42,6 +43,17 @@ class _Chain(nn.Module):
         """CDF at first_target + s, s < L, for every (head, channel) row -> [n_rows, L]."""
         return ops.bitparm_cdf_table(self.chain_params(), self.n_rows(), first_target, L)
 
+    def _host_chain(self, x):
+        """The four Bitparm layers on host copies of the parameters, with the reference's own ATen calls in the
+        reference's order (bitEstimator.py:21-26 / 136-141): the result is the reference's, bit for bit, on the same
+        host.  Load-time use only (a table has K*M*L entries)."""
+        for f in (self.f1, self.f2, self.f3):
+            h, b, a = f.h.detach().cpu(), f.b.detach().cpu(), f.a.detach().cpu()
+            x = x * F.softplus(h) + b
+            x = x + torch.tanh(x) * torch.tanh(a)
+        h, b = self.f4.h.detach().cpu(), self.f4.b.detach().cpu()
+        return torch.sigmoid(x * F.softplus(h) + b)
+
 
 class BitEstimator(_Chain):
     """Single-head estimator used for the hyper-latent z (bitEstimator.py:30-45); params [1,C,1,1]."""
@@ -51,6 +63,14 @@ class BitEstimator(_Chain):
         shape = (1, channel, 1, 1)
         self.f1, self.f2, self.f3 = _Bitparm(shape, False), _Bitparm(shape, False), _Bitparm(shape, False)
         self.f4 = _Bitparm(shape, True)
+
+    def table_host(self, lo: float, hi: float, L: int) -> torch.Tensor:
+        """[C, L] float table evaluated on the host exactly as the reference does it (abstract_model.py:277-283:
+        linspace targets, expanded -- not contiguous -- to [1, C, L, 1])."""
+        C = self.f1.h.numel()
+        targets = torch.linspace(lo, hi, L)
+        targets = targets.expand(C, L).unsqueeze(0).unsqueeze(-1)
+        return self._host_chain(targets).squeeze()
 
     def forward_nhwc(self, x, offset: float = 0.0):
         """x: NHWC [B,h,w,C] -> CDF(x + offset), same shape."""
@@ -76,6 +96,15 @@ class MultiHeadBitEstimator(_Chain):
         pshape = (nb_head, 1, channel, 1, 1)
         mk = lambda final: _Bitparm(pshape, final, bitparm_init_range, bitparm_init_mode)
         self.f1, self.f2, self.f3, self.f4 = mk(False), mk(False), mk(False), mk(True)
+
+    def table_host(self, lo: float, hi: float, L: int) -> torch.Tensor:
+        """[K, C, L] float table evaluated on the host exactly as the reference does it
+        (manynets_compressor.py:142-152: linspace targets as a contiguous [1, C, L, 1] against [K, 1, C, 1, 1]
+        parameters)."""
+        targets = torch.linspace(lo, hi, L)
+        targets = targets.expand(1, self.channel, L).unsqueeze(-1).contiguous()
+        table = self._host_chain(targets).squeeze(-1).squeeze(1)
+        return table.squeeze()
 
     def forward(self, x, offset: float = 0.0):
         """x: [B,C,h,w] -> [K,B,C,h,w] CDF values of every head (the network form of the competition)."""

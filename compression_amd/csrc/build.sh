@@ -4,7 +4,7 @@ set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 out="${MPC_OUT:-$here/../libmpc.so}"        # MPC_OUT / MPC_BUILD_DIR: side-by-side experimental builds
 bdir="${MPC_BUILD_DIR:-$here/build}"
-srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip conv_igemm_f16.hip deconv5s2_patch_f16.hip conv_igemm_x3.hip conv5s2_patch_x3.hip conv_rgb_out_f16.hip metrics.hip)
+srcs=(context.hip entropy_tables.hip prior_competition.hip rans.hip conv_igemm.hip conv_igemm_f16.hip deconv5s2_patch_f16.hip conv_igemm_x3.hip conv5s2_patch_x3.hip conv_rgb_out_f16.hip gdn.hip metrics.hip)
 objs=()
 mkdir -p "$bdir"
 pids=()

@@ -67,6 +67,9 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         ap = kwargs.pop("analysis_precision", None)
         if ap is not None:
             self.Encoder.precision = ap
+        # who evaluates the float CDF table: the HIP kernel ("device", default) or the reference's own ATen calls on the
+        # host at load time ("host": the reference's int16 table bit for bit), see update_entropy_table
+        self.table_authority = kwargs.pop("table_authority", "device")
         self.num_distributions = num_distributions
         self.dist_patch_size = dist_patch_size
         self.bitEstimators = MultiHeadBitEstimator(self.nchans_per_prior, nb_head=num_distributions,
@@ -77,11 +80,24 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         self._tables_fp = None
 
     # ---- tables -----------------------------------------------------------------------------
-    def update_entropy_table(self):
+    def update_entropy_table(self, authority=None):
         """Float CDF table [K,M,L] at the bin edges, its int16 renormalisation (torchac's rounding order) and
-        the two code-length LUTs of the competition (manynets_compressor.py:140-171)."""
+        the two code-length LUTs of the competition (manynets_compressor.py:140-171).
+
+        authority (default: the constructor's table_authority): "device" evaluates the Bitparm chain in a HIP kernel
+        (each transcendental correctly rounded; against a table built by PyTorch on a CPU, whose vector math library
+        is within 1 ulp, 1.5e-4 of the int16 entries differ by one); "host" evaluates it once, at load time, with the
+        reference's own ATen calls on the host and uploads it: the reference's table bit for bit, so that streams
+        are interchangeable with a decoder whose table the reference built on the same machine."""
+        authority = authority or self.table_authority
+        if authority not in ("device", "host"):
+            raise ValueError(f"table authority must be 'device' or 'host', got {authority!r}")
         K, M, L = self.num_distributions, self.out_channel_M, self._n_targets()
-        tf = self.bitEstimators.table(self.min_feat - 0.5, L).view(K, M, L)
+        if authority == "host":
+            dev = next(self.bitEstimators.parameters()).device
+            tf = self.bitEstimators.table_host(self.min_feat - 0.5, self.max_feat + 0.5, L).view(K, M, L).to(dev)
+        else:
+            tf = self.bitEstimators.table(self.min_feat - 0.5, L).view(K, M, L)
         self.entropy_table_float = tf
         self.entropy_table = ops.renorm_cast_cdf(tf, self.precision, _lib.MPC_ORDER_ROUND_THEN_ADD)
         self.entropy_table_cpu = self.entropy_table.cpu()

@@ -126,6 +126,20 @@ def sum_f32(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gdn_forward(x: torch.Tensor, beta: torch.Tensor, gamma: torch.Tensor, inverse: bool) -> torch.Tensor:
+    """GDN / IGDN layer on an NCHW (or 5-D [B, C, D, W, H]) fp32 tensor with the raw parameters (GDN.py:65-95)."""
+    x = _dev(x, torch.float32, "x")
+    if x.dim() not in (4, 5):
+        raise ValueError(f"gdn_forward: expected a 4-D or 5-D tensor, got {tuple(x.shape)}")
+    B, C = x.shape[:2]
+    if tuple(beta.shape) != (C,) or tuple(gamma.shape) != (C, C):
+        raise ValueError(f"gdn_forward: beta {tuple(beta.shape)} / gamma {tuple(gamma.shape)} do not fit {C} channels")
+    out = torch.empty_like(x)
+    context_for(x.device).call("mpc_gdn_forward", ptr(x), ptr(_dev(beta, torch.float32, "beta")),
+                               ptr(_dev(gamma, torch.float32, "gamma")), B, C, x[0, 0].numel(), int(bool(inverse)), ptr(out))
+    return out
+
+
 def clamp_sse(recon: torch.Tensor, target: Optional[torch.Tensor]):
     """-> (clamp(recon,0,1), float64[1] sum of squared errors vs target | None)."""
     _dev(recon, torch.float32, "recon")

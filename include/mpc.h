@@ -272,6 +272,13 @@ int mpc_conv_out_hw(const mpc_conv *conv, int H, int W, int *Ho, int *Wo);
  * NULL) receives the unrounded values and `out_round` the rounded ones. */
 int mpc_conv_forward(mpc_ctx *ctx, const mpc_conv *conv, const void *in, int B, int H, int W,
                      int flags, void *out, float *out_round);
+/* GDN / IGDN as a layer of its own on an NCHW fp32 tensor x [B, C, HW] (a 5-D input [B, C, D, W, H] is the same
+ * memory with HW = D*W*H, GDN.py:67-70): out = x / sqrt(beta_eff + gamma_eff . x^2) (inverse != 0: x * sqrt(...)), the
+ * raw parameters beta [C], gamma [C, C] reparametrised as in GDN.py:75-81, the channel mix on the exact fp32 matrix
+ * pipe.  C a multiple of 32.  Replaces GDN.forward (src/compression/models/GDN.py:65-95); inside the transforms the
+ * normalisation is fused into the producing convolution (mpc_conv_create with MPC_ACT_GDN / MPC_ACT_IGDN). */
+int mpc_gdn_forward(mpc_ctx *ctx, const float *x, const float *beta, const float *gamma, int B, int C, int64_t HW,
+                    int inverse, float *out);
 /* The last layer of g_s with the evaluation's clamp and squared error fused into its epilogue: xhat_nchw =
  * clamp(layer output, 0, 1) as fp32 NCHW and sse_dev[b] (device float64 [B], zeroed by this call) = sum over image b of
  * (xhat - target)^2 -- recon.clamp(0, 1) and the per-image MSE of the test harness (manynets_compressor.py:537-543,

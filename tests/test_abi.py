@@ -134,3 +134,27 @@ def test_mrs1_header_validation_on_the_host():
         ops.parse_mrs1_headers([good, forged(n_streams=5, sps=24 * M)], n_loc, M)
     with pytest.raises(ValueError):
         ops.parse_mrs1_headers([], n_loc, M)
+
+
+def test_host_authority_float_tables_equal_the_reference_capture(golden):
+    """The host-side evaluation of the learned CDF tables (table_authority="host": the reference's own ATen calls on
+    CPU copies of the parameters) against rows captured from the reference itself in the build container
+    (tests/golden/tables_std.npz, forward_hyperprior.npz): bit for bit.  No GPU is involved in that evaluation."""
+    import hashlib
+    import numpy as np
+    import torch  # noqa: F401
+    from compression_amd.bitEstimator import BitEstimator, MultiHeadBitEstimator
+    from tests import synth
+    N, M, K = 192, 256, 64
+    g = golden("tables_std")
+    sd = synth.manypriors_state_dict(234, N, M, K, spread=True)
+    est = MultiHeadBitEstimator(M, nb_head=K)
+    est.load_state_dict({k[len("bitEstimators."):]: v for k, v in sd.items() if k.startswith("bitEstimators.")})
+    tf = est.table_host(-127.5, 128.5, 257)
+    assert tuple(tf.shape) == (K, M, 257)
+    assert hashlib.sha256(tf.contiguous().numpy().tobytes()).hexdigest() == str(g["sha_table_f"])
+    gh = golden("forward_hyperprior")
+    sdh = synth.hyperprior_state_dict(236, N, M)
+    zest = BitEstimator(N)
+    zest.load_state_dict({k[len("bitEstimator_z."):]: v for k, v in sdh.items() if k.startswith("bitEstimator_z.")})
+    assert np.array_equal(zest.table_host(-127.5, 128.5, 257).numpy(), gh["z_table_f"])

@@ -90,7 +90,7 @@ def check_indices(total_ref, idx_dev, skip_locs, what):
     print(f"{what}: {len(mism)} / {got.numel()} prior indices differ from the oracle" +
           (f" (largest gap between the two candidates: {max(gaps):.1e} bits)" if mism else ""))
     assert all(g < TIE_BITS for g in gaps)
-    assert len(mism) <= max(2, int(2e-3 * got.numel()))
+    assert len(mism) <= max(1, int(1e-5 * got.numel()))           # (measured: none at any of the benchmark's sizes)
     return len(mism)
 
 
@@ -267,3 +267,39 @@ def test_device_tables_against_reference_capture(dev, sd, golden):
     for order, key in ((0, "table_torchac_rows"), (1, "table_inrepo_rows")):
         got = ops.renorm_cast_cdf(tf_ref.to(dev), 16, order).cpu()
         assert torch.equal(got, torch.from_numpy(g[key]))
+
+
+def test_host_authority_tables_equal_the_oracle_bit_for_bit(dev, sd):
+    """table_authority="host": the float chain is evaluated with the reference's own ATen calls on this machine's CPU,
+    so the float table and the int16 tables in BOTH rounding orders equal the oracle's, evaluated live on the same host,
+    in every entry (the device-built default differs in 1.5e-4 of the int16 entries, see the test above); so does the
+    hyperprior's z table.  The range-widened table (513 targets) is covered too."""
+    import compression_amd as ca
+    from compression_amd import abstract_model
+    m = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=K, table_authority="host")
+    m.load_state_dict(sd)
+    m.eval()
+    assert m.update_entropy_table()
+    tf = O.entropy_table_float(sd, M)
+    assert torch.equal(m.entropy_table_float.cpu(), tf)
+    assert torch.equal(m.entropy_table.cpu(), O.renorm_cast_cdf(tf, 16, O.ORDER_ROUND_THEN_ADD))
+    assert torch.equal(abstract_model._renorm_cast_cdf_(m.entropy_table_float, 16).cpu(),
+                       O.renorm_cast_cdf(tf, 16, O.ORDER_ADD_THEN_ROUND))
+    m._widen_tables()                                   # [-255, 256]: the reference's range doubling
+    tf2 = O.entropy_table_float(sd, M, -255, 256)
+    assert m.entropy_table.shape[-1] == 513
+    assert torch.equal(m.entropy_table.cpu(), O.renorm_cast_cdf(tf2, 16, O.ORDER_ROUND_THEN_ADD))
+    # the per-call override wins over the constructor's choice, and the device table stays within its documented tie set
+    m.min_feat, m.max_feat = -127, 128
+    m.update_entropy_table(authority="device")
+    d = m.entropy_table.cpu().int() - O.renorm_cast_cdf(tf, 16, O.ORDER_ROUND_THEN_ADD).int()
+    assert d.abs().max().item() <= 1 and (d != 0).float().mean().item() < 5e-4
+    # hyperprior: factorised z table, in-repo rounding order
+    hsd = synth.hyperprior_state_dict(236, N, M)
+    hm = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M, table_authority="host")
+    hm.load_state_dict(hsd)
+    hm.eval()
+    hm.update_entropy_table()
+    ztf = O.z_table_float(hsd, N)
+    assert torch.equal(hm.z_entropy_table_float.cpu(), ztf)
+    assert torch.equal(hm.z_entropy_table.cpu(), O.renorm_cast_cdf(ztf, 16, O.ORDER_ADD_THEN_ROUND))

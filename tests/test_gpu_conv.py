@@ -111,6 +111,31 @@ def test_fused_gdn_uses_gamma_rows_not_columns(dev, ops, inverse):
     assert rel_err(wrong, want) > 1e-2
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("shape", [(2, 192, 13, 21), (1, 128, 5, 7), (1, 256, 33, 4), (3, 32, 1, 1), (2, 64, 3, 5, 6)])
+def test_gdn_layer_called_directly(dev, inverse, shape):
+    """The GDN module as a layer of its own (GDN.py:65-95) against the oracle's restatement, 4-D and 5-D inputs (the
+    5-D tensor is folded to [B, C, D*W, H] and unfolded again), ragged pixel counts, asymmetric gamma, parameters below
+    their lower bounds (they are clamped, :75-81).  The channel mix is an fp32 fma chain in another order than ATen's
+    1x1 convolution: agreement to fp32 rounding."""
+    from compression_amd.GDN import GDN
+    g = torch.Generator().manual_seed(60 + len(shape))
+    C = shape[1]
+    layer = GDN(C, inverse=inverse)
+    layer.beta.data = 0.5 + torch.rand(C, generator=g)
+    layer.beta.data[::7] = 0.0                                     # below the bound: beta_eff = 1e-6
+    gamma = 0.3 * torch.rand(C, C, generator=g) * (torch.arange(C).view(-1, 1) / C + 0.1)
+    gamma[3::5, 1::4] = -1.0                                       # below the bound: gamma_eff = 0
+    layer.gamma.data = gamma
+    x = torch.randn(*shape, generator=g) * 3
+    x4 = x if x.dim() == 4 else x.view(shape[0], C, shape[2] * shape[3], shape[4])
+    want = O.gdn(x4, layer.beta.data, layer.gamma.data, inverse=inverse).view(shape)
+    got = layer.to(dev)(x.to(dev)).cpu()
+    assert got.shape == x.shape
+    assert rel_err(got, want) < 2e-6
+    assert rel_err(O.gdn(x4, layer.beta.data.cpu(), layer.gamma.data.cpu().t().contiguous(), inverse=inverse).view(shape), want) > 1e-3
+
+
 def test_last_layer_to_rgb_nchw_clamped(dev, ops):
     from compression_amd import _lib
     g = torch.Generator().manual_seed(7)
