@@ -411,6 +411,29 @@ def run_rank(args):
     if args.mode == "codec" and not args.serial:
         from compression_amd.pipeline import CodecPipeline
         pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis)
+    fpipe = None
+    if args.mode != "codec" and not args.serial:
+        from compression_amd.pipeline import ForwardPipeline
+        fpipe = ForwardPipeline(model, dev, depth=2)
+
+    def forward_stats(out, stream):
+        """Statistics of one finished forward, formed on the stream that holds its tensors."""
+        with torch.cuda.stream(stream):
+            xhat = out["reconstructed_image"]
+            _, sse = ops.clamp_sse_per_image(xhat, target)
+            bits = out["host_bits"]["feature"]                # (host numbers: no blocking read of a device scalar)
+            key = stream.cuda_stream
+            a = accs.get(key)
+            if a is None:
+                a = accs[key] = StatsAccumulator(device=dev)
+            a.add_batch_device(sse, 3 * H * W, bits=bits, pixels=B * H * W, nbytes=bits / 8, seconds=state["seconds"],
+                               side_bits=out["host_bits"]["sidestring"], reset=True)
+            state["acc"] = a
+        return xhat
+
+    def pipelined_forward_step():
+        r = fpipe.submit(x)
+        return None if r is None else forward_stats(r[0], fpipe.result_stream)
 
     def pipelined_codec_step():
         r = pipe.submit(x, target=target)
@@ -418,6 +441,12 @@ def run_rank(args):
 
     def drain():
         """-> x_hat of the batch still in flight, if any (the pipeline is empty afterwards)."""
+        if fpipe is not None:
+            last = None
+            for out, _ in fpipe.flush():
+                last = forward_stats(out, fpipe.result_stream)
+            fpipe.synchronize()
+            return last
         if pipe is None:
             return None
         r = pipe.flush()
@@ -427,7 +456,10 @@ def run_rank(args):
     def keep_last(new, old):
         return old if new is None else new
 
-    step = forward_step if args.mode != "codec" else (serial_codec_step if args.serial else pipelined_codec_step)
+    if args.mode != "codec":
+        step = forward_step if args.serial else pipelined_forward_step
+    else:
+        step = serial_codec_step if args.serial else pipelined_codec_step
 
     def barrier():
         if dist is not None:
@@ -442,7 +474,7 @@ def run_rank(args):
 
     xhat = None
     wprof = ops.PROFILER = ops.Profiler()
-    n_warm = max(args.warmup, 4 if pipe is not None else 1)   # (two batches per stream: torch's allocator has every block it will need)
+    n_warm = max(args.warmup, 4 if (pipe is not None or fpipe is not None) else 1)   # (two batches per stream: torch's allocator has every block it will need)
     for _ in range(n_warm):
         t = time.perf_counter()
         xhat = keep_last(step(), xhat)                      # (kept, as in the timed loop: the allocator reaches its steady state here)
@@ -549,7 +581,7 @@ def run_rank(args):
                                f"random-init weights with spread priors, {args.data} input",
                    "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
                    "parallelism": f"image-sharded x{world}, statistics all-reduce only",
-                   "batches_in_flight": 2 if pipe is not None else 1, "warmup_steps_run": n_warm},
+                   "batches_in_flight": 2 if (pipe is not None or fpipe is not None) else 1, "warmup_steps_run": n_warm},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,

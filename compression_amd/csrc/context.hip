@@ -200,9 +200,12 @@ __global__ void clamp_sse_kernel(const float *__restrict__ recon, const float *_
             acc += (double)(d * d);
         }
     }
-    if (sse) {
+    if (sse) {                                              // one atomic per workgroup: they all go to one address
+        __shared__ double part[4];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(sse, acc);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse, part[0] + part[1] + part[2] + part[3]);
     }
 }
 
@@ -239,7 +242,7 @@ int mpc_clamp_sse(mpc_ctx *ctx, const float *recon, const float *target, int64_t
     MPC_REQUIRE(ctx, recon && n > 0 && (xhat || (sse_dev && target)), "clamp_sse: bad arguments");
     if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double), ctx->stream));
     int64_t blocks = mpc_cdiv(n, 256 * 4);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 512) blocks = 512;
     const int aligned16 = (((uintptr_t)recon | (uintptr_t)target | (uintptr_t)xhat) & 15) == 0;
     clamp_sse_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(recon, sse_dev ? target : nullptr, n, xhat, sse_dev, aligned16, 0);
     MPC_CHECK_LAUNCH(ctx, "clamp_sse");
@@ -253,7 +256,7 @@ int mpc_clamp_sse_batched(mpc_ctx *ctx, const float *recon, const float *target,
                 "clamp_sse_batched: bad arguments");
     if (sse_dev) MPC_HIP(ctx, hipMemsetAsync(sse_dev, 0, sizeof(double) * n_images, ctx->stream));
     int64_t blocks = mpc_cdiv(n_per_image, 256 * 4);
-    const int64_t cap = mpc_cdiv(4096, n_images);
+    const int64_t cap = mpc_cdiv(1024, n_images);
     if (blocks > cap) blocks = cap;
     const int aligned16 = ((((uintptr_t)recon | (uintptr_t)target | (uintptr_t)xhat) & 15) == 0) && (n_per_image % 4 == 0);
     clamp_sse_kernel<<<dim3((unsigned)blocks, (unsigned)n_images), dim3(256), 0, ctx->stream>>>(

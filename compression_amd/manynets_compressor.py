@@ -160,53 +160,86 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         with entropy_coding), side-string cost (manynets_compressor.py:502-644)."""
         if self.training:
             return self._forward_train(input_image, **kwargs)
+        while True:
+            out = self.forward_finish(self.forward_begin(input_image))
+            if out is not None:
+                return out
+            self._widen_tables()                         # like the reference (manynets_compressor.py:212-227), then again
+
+    def forward_begin(self, input_image):
+        """Enqueues the whole eval-mode forward on the current stream and returns at once: g_a -> competition -> sum of
+        the winners' bits -> (copy of the index map, the clamped count and that sum to page-locked memory) -> g_s and
+        the loss.  -> a job for forward_host_part / forward_finish.  The host's part (which priors were used, the side
+        string's candidates: the LZMA call alone is ~1 ms) only needs the copy, so it runs while g_s does."""
         self._ensure_tables()
         x = input_image.contiguous()
         B, _, H, W = x.shape
-        npix = B * H * W
-        # Enqueue order: g_a -> competition -> (copy of the index map and the clamped count to the host) -> g_s and
-        # the loss.  The host then waits for the copy only, and does its part (which priors were used, the side
-        # string's candidates: the LZMA call alone is ~1 ms) while g_s runs.
-        while True:
-            yhat, sym4, nclamp = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1,
-                                                              keep_rounded=True)
-            _, h, w, M = yhat.shape
-            sym = sym4.view(-1, M)
-            idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
-            n_loc = idx.numel()
-            host = self._meta_host(n_loc + 1)
-            host[:n_loc].copy_(idx.view(-1), non_blocking=True)
-            host[n_loc:].copy_(nclamp.view(-1)[:1], non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record()
-            recon = self.Decoder.forward_nhwc(yhat)
-            xhat, visual_loss = self._visual_loss(recon, x)
-            copied.synchronize()                         # g_a and the competition have finished; g_s is still running
-            if int(host[n_loc]) == 0:
-                break
-            self._widen_tables()                         # like the reference (manynets_compressor.py:212-227), then again
-        dist_select = idx.view(B, h, w)
-        self.last_dist_select = dist_select          # the prior index map of the last forward (int32 [B,h,w], on the GPU)
-        idx_cpu = host[:n_loc].clone().view(B, h, w)
+        yhat, sym4, nclamp = self.Encoder.forward_symbols(ops.nchw_to_nhwc(x, 4), self.min_feat, self._n_targets() - 1,
+                                                          keep_rounded=True)
+        _, h, w, M = yhat.shape
+        sym = sym4.view(-1, M)
+        idx, minbits, _ = ops.prior_argmin(sym, self._lut_log2)
+        bits = ops.sum_f32(minbits)                       # float64 [1]
+        n_loc = idx.numel()
+        host = self._meta_host(n_loc + 3, "forward")      # index map | clamped count | the sum's two words
+        host[:n_loc].copy_(idx.view(-1), non_blocking=True)
+        host[n_loc:n_loc + 1].copy_(nclamp.view(-1)[:1], non_blocking=True)
+        host[n_loc + 1:].copy_(bits.view(torch.int32), non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        recon = self.Decoder.forward_nhwc(yhat)
+        xhat, visual_loss = self._visual_loss(recon, x)
+        return dict(x=x, B=B, H=H, W=W, h=h, w=w, sym=sym, idx=idx, bits=bits, host=host, copied=copied, xhat=xhat,
+                    visual_loss=visual_loss, n_loc=n_loc, try_png=TRY_PNG_SIDESTRING)
+
+    @staticmethod
+    def forward_host_part(job):
+        """The host's share of a forward, free of model state (a worker thread may run it; the event wait, numpy and
+        LZMA all release the interpreter lock): waits for the job's copy, -> (clamped count, index map on the host,
+        priors used, side-string bits, the competition's bit estimate).  Everything the page-locked buffer held is
+        copied out of it here: the next job on the same stream overwrites it."""
+        job["copied"].synchronize()                      # g_a and the competition have finished; g_s may still be running
+        host, n_loc = job["host"], job["n_loc"]
+        nclamp = int(host[n_loc])
+        bits = float(host[n_loc + 1:].numpy().view(np.float64)[0])
+        idx_cpu = host[:n_loc].clone().view(job["B"], job["h"], job["w"])
+        if nclamp:
+            return nclamp, idx_cpu, None, None, bits
         used = np.unique(idx_cpu.numpy())
+        side_bits = pt_helpers.get_num_bits(idx_cpu, integers=True, try_png=job["try_png"])
+        return nclamp, idx_cpu, used, side_bits, bits
+
+    def forward_finish(self, job, host_part=None):
+        """-> the forward's dictionary (manynets_compressor.py:636-644), or None if a latent fell outside the tables'
+        range (the caller widens the tables and runs the forward again, as the reference does).  host_part:
+        forward_host_part(job) if it has been computed elsewhere already."""
+        nclamp, idx_cpu, used, side_bits, bits_host = host_part if host_part is not None else self.forward_host_part(job)
+        if nclamp:
+            return None
+        B, H, W, idx, x = job["B"], job["H"], job["W"], job["idx"], job["x"]
+        npix = B * H * W
+        self.last_dist_select = idx.view(B, job["h"], job["w"])   # the prior index map of the last forward (int32, on the GPU)
         self.dists_last_use[used] = 0
         self.dists_last_use[np.setdiff1d(np.arange(self.num_distributions), used, assume_unique=True)] += 1
         if not self.entropy_coding:
-            total_bits_feature = ops.sum_f32(minbits).to(torch.float32).reshape(())
+            total_bits_feature = job["bits"].to(torch.float32).reshape(())
         else:
-            streams, _ = self._encode_symbols(sym, idx, B, float(ops.sum_f32(minbits).item()) / 8 / B, verify=True)
-            total_bits_feature = torch.tensor(float(sum(len(s) for s in streams) * 8), device=x.device)
-        bpp_sidestring = torch.tensor(pt_helpers.get_num_bits(idx_cpu, integers=True, try_png=TRY_PNG_SIDESTRING),
-                                      dtype=torch.float32, device=x.device) / npix
+            streams, _ = self._encode_symbols(job["sym"], idx, B, bits_host / 8 / B, verify=True)
+            bits_host = float(sum(len(s) for s in streams) * 8)
+            total_bits_feature = torch.tensor(bits_host, device=x.device)
+        bpp_sidestring = torch.tensor(side_bits, dtype=torch.float32, device=x.device) / npix
         bpp_feature = total_bits_feature / npix
         return {
-            "reconstructed_image": xhat,
-            "visual_loss": visual_loss,
+            "reconstructed_image": job["xhat"],
+            "visual_loss": job["visual_loss"],
             "bpp_feature": bpp_feature,
             "bpp_sidestring": bpp_sidestring,
             "bpp": bpp_feature + bpp_sidestring,
             "used_dists": used.tolist(),
             "num_forced_dists": 0,
+            # not in the reference's dictionary: the two bit counts as host numbers (they are on the host already), for
+            # callers that keep several forwards in flight and must not block on a device scalar
+            "host_bits": {"feature": bits_host, "sidestring": float(side_bits)},
         }
 
     def _forward_train(self, input_image, quant_noise=None, **kwargs):

@@ -101,3 +101,71 @@ class CodecPipeline:
     def synchronize(self):
         for s in self.streams:
             s.synchronize()
+
+
+class ForwardPipeline:
+    """Throughput mode of the eval-mode forward (the call the reference's test harness makes once per image,
+    src/compression/tests.py:356): `depth` batches in flight on alternating streams, the host's share of each
+    (waiting for the index map, which priors were used, the side string's LZMA call) on a worker thread, so that the GPU
+    goes from one batch's g_s straight into the next batch's g_a.  submit() returns the dictionary of the batch submitted
+    depth - 1 calls earlier: same keys and values as model(x).  A batch whose latents fall outside the tables' range
+    is run again after the tables have been widened, like model(x) does; the batches behind it in the pipeline are
+    run again too (their rates were estimated with the narrower table)."""
+
+    def __init__(self, model, device, depth=2):
+        from concurrent.futures import ThreadPoolExecutor
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        self.model = model
+        self.device = torch.device(device)
+        self.depth = depth
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(min(depth, 2))]
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.queue = []              # (input, job, future of its host part, tag, stream), oldest first
+        self.count = 0
+        for s in self.streams:
+            s.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _begin(self, x, tag):
+        stream = self.streams[self.count % len(self.streams)]
+        self.count += 1
+        with torch.cuda.stream(stream):
+            job = self.model.forward_begin(x)
+        self.queue.append((x, job, self.pool.submit(self.model.forward_host_part, job), tag, stream))
+
+    def _finish_oldest(self):
+        x, job, future, tag, stream = self.queue.pop(0)
+        with torch.cuda.stream(stream):
+            out = self.model.forward_finish(job, future.result())
+            if out is None:                                   # out of the tables' range: widen, then everything in flight again
+                redo = [(q[0], q[3]) for q in self.queue]
+                for q in self.queue:
+                    q[2].result()
+                self.queue = []
+                self.model._widen_tables()
+                out = self.model(x)
+                for rx, rtag in redo:
+                    self._begin(rx, rtag)
+        self.result_stream = stream
+        return out, tag
+
+    def submit(self, x, tag=None):
+        """-> None while the pipeline fills, else (the forward's dictionary, tag) of the oldest batch in flight; its
+        tensors are complete on the stream `result_stream`."""
+        done = self._finish_oldest() if len(self.queue) >= self.depth else None
+        self._begin(x, tag)
+        return done
+
+    def flush(self):
+        """-> list of (dictionary, tag) of everything still in flight, oldest first."""
+        out = []
+        while self.queue:
+            out.append(self._finish_oldest())
+        return out
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        self.pool.shutdown(wait=True)

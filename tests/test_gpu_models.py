@@ -456,3 +456,55 @@ def test_scored_synthesis_matches_clamp_and_sse_pass(model_fp16, dev, hw):
     torch.cuda.synchronize()
     assert torch.equal(xhat, want_xhat)
     assert torch.allclose(job["sse"], want_sse, rtol=1e-10, atol=0.0)
+
+
+def test_forward_pipeline_matches_one_forward_at_a_time(model_fp16, dev):
+    """ForwardPipeline (two batches in flight, the host's share on a worker thread) returns, for every batch, the
+    dictionary that model(x) returns: same reconstruction bits, same rate and side-string cost to the bit, same priors
+    used, in submission order -- including a batch whose latents leave the tables' range (the tables are widened and
+    the batches in flight run again, as model(x) would)."""
+    from compression_amd.pipeline import ForwardPipeline
+    m = model_fp16
+    xs = [synth.rand_image(300 + i, 2, 64, 96).to(dev) for i in range(5)]
+    want = [m(x) for x in xs]
+    torch.cuda.synchronize()
+    pipe = ForwardPipeline(m, dev, depth=2)
+    got = []
+    for i, x in enumerate(xs):
+        r = pipe.submit(x, tag=i)
+        if r is not None:
+            got.append(r)
+    got += pipe.flush()
+    pipe.synchronize()
+    assert [t for _, t in got] == list(range(5))
+    for (out, _), ref in zip(got, want):
+        assert torch.equal(out["reconstructed_image"], ref["reconstructed_image"])
+        for key in ("bpp_feature", "bpp_sidestring", "bpp", "visual_loss"):
+            assert float(out[key]) == float(ref[key]), key
+        assert out["used_dists"] == ref["used_dists"]
+    pipe.close()
+    # latents outside the tables' range: two models with a narrow range, one called batch by batch, one through the pipeline
+    import compression_amd as ca
+    sd8 = synth.manypriors_state_dict(234, N, M, 8, spread=True)
+    models = []
+    for _ in range(2):
+        n = ca.init_model("ManyPriors", dev, out_channel_N=N, out_channel_M=M, num_distributions=8, min_feat=-3, max_feat=4)
+        n.load_state_dict(sd8)
+        models.append(n.eval())
+    ys = [synth.rand_image(310 + i, 1, 64, 64).to(dev) for i in range(3)]
+    want = [models[0](y) for y in ys]
+    assert models[0].max_feat > 4, "these inputs were meant to leave the tables' range"
+    pipe = ForwardPipeline(models[1], dev, depth=2)
+    got = []
+    for i, y in enumerate(ys):
+        r = pipe.submit(y, tag=i)
+        if r is not None:
+            got.append(r)
+    got += pipe.flush()
+    pipe.synchronize()
+    pipe.close()
+    assert [t for _, t in got] == [0, 1, 2]
+    assert (models[1].min_feat, models[1].max_feat) == (models[0].min_feat, models[0].max_feat)
+    for (out, _), ref in zip(got, want):
+        assert float(out["bpp"]) == float(ref["bpp"])
+        assert torch.equal(out["reconstructed_image"], ref["reconstructed_image"])
