@@ -126,6 +126,10 @@ def parse(argv=None):
                     help="codec workloads: one batch after the other on one stream (default: two batches in flight on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=40, help="images of the CPU baseline's sample at the larger thread count")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0,
+                    help="--gpus N launcher: seconds after which ranks that are still running are ended")
+    ap.add_argument("--fail-rank", type=int, default=None,
+                    help="dry run only: this rank exits with an error before it joins the process group (launcher test)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: gloo ranks on the CPU with a stub step, to rehearse the launcher and the statistics path")
     args = ap.parse_args(argv)
@@ -163,21 +167,45 @@ def spawn_ranks(args, argv):
         if n < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible", file=sys.stderr)
             return 2
+    import tempfile
     port = free_port()
     cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
     procs = []
-    for r in range(args.gpus):
-        procs.append(subprocess.Popen(cmd, env=child_env(r, args.gpus, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
-    if any(rcs) or not lines:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    # rank 0 writes to a file, not a pipe: nobody has to drain it while the ranks are polled
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(args.gpus):
+            env = child_env(r, args.gpus, port)
+            if args.fail_rank == r:
+                env["MPC_BENCH_FAIL_EARLY"] = "1"
+            procs.append(subprocess.Popen(cmd, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+        # All ranks are polled together.  The first one that exits with an error ends the job: the others may be sitting
+        # in the process group's rendezvous or in a barrier that can never complete, holding their GPUs.
+        deadline = time.monotonic() + args.launch_timeout
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            failed = next((p for p in procs if p.poll() not in (None, 0)), None)
+            if failed is None and time.monotonic() > deadline:
+                print(f"bench.py: ranks still running after {args.launch_timeout:.0f} s, giving up", file=sys.stderr)
+                failed = next(p for p in procs if p.poll() is None)
+            if failed is None:
+                time.sleep(0.05)
+        if failed is not None:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        rcs = [p.returncode for p in procs]
+        out0.seek(0)
+        lines = [l for l in out0.read().splitlines() if l.startswith("{")]
+    if failed is not None or any(rcs) or not lines:
         print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
-        return next((rc for rc in rcs if rc), 1)
+        return next((rc for rc in rcs if rc and rc > 0), 1)
     print(lines[-1])
     return 0
 
@@ -312,6 +340,9 @@ def run_dry(args, rank, world):
     image-dependent numbers through StatsAccumulator and the all-reduce, and rank 0 prints the reduced sums."""
     from compression_amd.distributed import StatsAccumulator
     dev = device_for(int(os.environ.get("LOCAL_RANK", "0")), True)
+    if os.environ.get("MPC_BENCH_FAIL_EARLY"):              # (launcher test: a rank that dies before the rendezvous)
+        print(f"bench.py: rank {rank} fails on request", file=sys.stderr)
+        return 3
     dist = init_distributed(args, dev, world)
     H, W = args.height, args.width
     t0 = time.perf_counter()

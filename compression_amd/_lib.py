@@ -76,6 +76,10 @@ SIGNATURES = {
                                            c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_rans_decode_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int,
                                         c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "mpc_rans_encode_laplace": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int64, c_int, c_int, c_int,
+                                        c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mpc_rans_decode_laplace": (c_int, [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p, c_int, c_int64,
+                                        c_int, c_int, c_int, c_void_p, c_void_p]),
     "mpc_conv_create": (c_int, [c_void_p, POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "mpc_conv_destroy": (c_int, [c_void_p]),
     "mpc_conv_out_hw": (c_int, [c_void_p, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

@@ -153,22 +153,29 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
 
     def _main_rows(self, zhat):
         """Per-element int16 Laplace(0, sigma) CDF rows of the main stream, in NHWC element order, as a
-        [n_loc, M, L] table (abstract_model.py:402-416; the rows are computed on the device, 514 bytes per
-        symbol, and never leave it)."""
+        [n_loc, M, L] table (abstract_model.py:402-416): the tensor the reference hands to torchac, 514 bytes per
+        symbol.  For inspection and tests only -- encode() and decode() never materialise it."""
         sigma = self.priorDecoder.forward_nhwc(zhat)
         L = self._main_L()
         rows = ops.laplace_cdf_rows(sigma.reshape(-1), self.min_feat_gaussian - 0.5, L, self.precision)
         return sigma, rows.view(-1, self.out_channel_M, L)
 
-    def encode(self, input_image, entropy_coding=True):
-        """One image -> [main string, z string, H, W] (abstract_model.py:370-454); with entropy_coding=False the
-        two int16 symbol vectors in the reference's orders (y: NCHW flattened, z: location-major).  The strings are
-        MRS1 rANS containers, not torchac bytes.  H and W must be multiples of 64."""
+    def _z_table(self):
+        return self.z_entropy_table.view(1, self.out_channel_N, -1).contiguous()
+
+    def encode_batch(self, input_image, entropy_coding=True):
+        """B equally sized images -> a list of B bitstreams [main string, z string, H, W] (abstract_model.py:370-454,
+        batched); with entropy_coding=False the two int16 symbol tensors, one row per image, in the reference's
+        orders (y: NCHW flattened, z: location-major).  The strings are MRS1 rANS containers, not torchac bytes.
+        H and W must be multiples of 64.
+
+        The main stream is coded under per-element Laplace(0, sigma) rows that are evaluated where they are needed
+        (mpc_rans_encode_laplace: two row entries per symbol) -- the reference materialises all of them
+        (abstract_model.py:409-416, 514 bytes per symbol); here the only per-symbol scratch is the coder's 4-byte
+        (start, frequency) word."""
         self._require_eval()
         x = input_image.contiguous()
         B, _, H, W = x.shape
-        if B != 1:
-            raise ValueError("encode() handles one image per call like the reference")
         y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
         _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
         sym_y, clamp_y = ops.latent_to_symbols(yhat, self.min_feat_gaussian, self.q_intv, self._main_L() - 1)
@@ -177,21 +184,56 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
             raise ValueError("encode: a latent falls outside the CDF tables' range "
                              f"[{self.min_feat_gaussian},{self.max_feat_gaussian}] / [{self.min_feat},{self.max_feat}]")
         _, h, w, M = yhat.shape
+        N = self.out_channel_N
         if not entropy_coding:
-            return sym_y.view(h, w, M).permute(2, 0, 1).reshape(-1), sym_z.reshape(-1)
+            return sym_y.view(B, h, w, M).permute(0, 3, 1, 2).reshape(B, -1), sym_z.reshape(B, -1)
         if H % 64 or W % 64:
             raise ValueError("entropy-coded encode needs H and W to be multiples of 64")
         self.update_entropy_table()                     # small (N x L); keeps the z table in step with the parameters
-        sigma, rows = self._main_rows(zhat)
-        n_loc = h * w
-        idx = torch.arange(n_loc, dtype=torch.int32, device=x.device)       # every location has a table of its own
-        est = float(ops.laplace_bits_total(yhat, sigma).item()) / 8
-        main = ops.rans_encode_to_bytes(rows, idx, sym_y, 1, est)[0]
-        zt = self.z_entropy_table.view(1, self.out_channel_N, -1).contiguous()
-        n_zloc = sym_z.numel() // self.out_channel_N
-        zidx = torch.zeros(n_zloc, dtype=torch.int32, device=x.device)
-        zstr = ops.rans_encode_to_bytes(zt, zidx, sym_z, 1, float(sym_z.numel()))[0]
-        return [main, zstr, H, W]
+        sigma = self.priorDecoder.forward_nhwc(zhat)
+        est = float(ops.laplace_bits_total(yhat, sigma).item()) / 8 / B
+        mains = ops.rans_encode_laplace_to_bytes(sigma, sym_y, B, M, self.min_feat_gaussian - 0.5, self._main_L(),
+                                                 self.precision, est)
+        n_zloc = sym_z.numel() // (B * N)
+        zidx = torch.zeros(B * n_zloc, dtype=torch.int32, device=x.device)
+        zstrs = ops.rans_encode_to_bytes(self._z_table(), zidx, sym_z, B, float(n_zloc * N))
+        return [[mains[i], zstrs[i], H, W] for i in range(B)]
+
+    def encode(self, input_image, entropy_coding=True):
+        """One image -> [main string, z string, H, W] (abstract_model.py:370-454); with entropy_coding=False the
+        two int16 symbol vectors in the reference's orders.  See encode_batch."""
+        if input_image.shape[0] != 1:
+            raise ValueError("encode() handles one image per call like the reference; encode_batch() takes more")
+        out = self.encode_batch(input_image, entropy_coding)
+        return out[0] if entropy_coding else (out[0].reshape(-1), out[1].reshape(-1))
+
+    def decode_batch(self, bitstreams):
+        """A list of B bitstreams [main string, z string, H, W] of equally sized images -> reconstruction [B, 3, H, W]
+        (NCHW, unclamped).  The z strings are decoded first; sigma = h_s(z_hat) then gives the decoder of the main
+        strings its rows (mpc_rans_decode_laplace), exactly as the encoder saw them."""
+        self._require_eval()
+        B = len(bitstreams)
+        if B == 0:
+            raise ValueError("decode_batch: no bitstream given")
+        H, W = bitstreams[0][2], bitstreams[0][3]
+        if any((b[2], b[3]) != (H, W) for b in bitstreams):
+            raise ValueError("decode_batch: all images of one call must have one size")
+        if H % 64 or W % 64:
+            raise ValueError("decode needs H and W to be multiples of 64")
+        dev = next(self.parameters()).device
+        self.update_entropy_table()
+        (h, w), (zh, zw) = self._latent_hw(H, W)
+        N, M = self.out_channel_N, self.out_channel_M
+        zidx = torch.zeros(B * zh * zw, dtype=torch.int32, device=dev)
+        sym_z = ops.rans_decode_from_bytes(self._z_table(), zidx, [b[1] for b in bitstreams])
+        zhat = ops.symbols_to_latent(sym_z.view(B, zh, zw, N), self.min_feat, self.q_intv)
+        sigma = self.priorDecoder.forward_nhwc(zhat)
+        if tuple(sigma.shape) != (B, h, w, M):
+            raise ValueError("decode: the z string does not match the image size")
+        sym_y = ops.rans_decode_laplace_from_bytes(sigma, [b[0] for b in bitstreams], M, self.min_feat_gaussian - 0.5,
+                                                   self._main_L(), self.precision)
+        yhat = ops.symbols_to_latent(sym_y.view(B, h, w, M), self.min_feat_gaussian, self.q_intv)
+        return self.Decoder.forward_nhwc(yhat)
 
     def decode(self, bitstream):
         """[main string, z string, H, W] -> reconstruction (NCHW, unclamped); a tensor is taken as the latent and
@@ -199,23 +241,7 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         mis-sizes z; this one inverts encode().)"""
         if isinstance(bitstream, torch.Tensor):
             return self.Decoder(bitstream)
-        self._require_eval()
-        main, zstr, H, W = bitstream
-        if H % 64 or W % 64:
-            raise ValueError("decode needs H and W to be multiples of 64")
-        dev = next(self.parameters()).device
-        self.update_entropy_table()
-        (h, w), (zh, zw) = self._latent_hw(H, W)
-        N, M = self.out_channel_N, self.out_channel_M
-        zt = self.z_entropy_table.view(1, N, -1).contiguous()
-        sym_z = ops.rans_decode_from_bytes(zt, torch.zeros(zh * zw, dtype=torch.int32, device=dev), [zstr])
-        zhat = ops.symbols_to_latent(sym_z.view(1, zh, zw, N), self.min_feat, self.q_intv)
-        _, rows = self._main_rows(zhat)
-        if rows.shape[0] != h * w:
-            raise ValueError("decode: the z string does not match the image size")
-        sym_y = ops.rans_decode_from_bytes(rows, torch.arange(h * w, dtype=torch.int32, device=dev), [main])
-        yhat = ops.symbols_to_latent(sym_y.view(1, h, w, M), self.min_feat_gaussian, self.q_intv)
-        return self.Decoder.forward_nhwc(yhat)
+        return self.decode_batch([bitstream])
 
     def compress(self, input_image):
         """-> (round(y), round(z)) as NCHW tensors (abstract_model.py:733-738)."""

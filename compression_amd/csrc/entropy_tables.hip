@@ -68,8 +68,7 @@ __global__ void bitparm_eval_kernel(const float *__restrict__ prep, int64_t n_ro
     out[i] = bitparm_chain(__fadd_rn(x[i], offset), prep + r * PREP);
 }
 
-// float -> int16 the way a vectorised x86 cast does it: through int32, keeping the low 16 bits.
-__device__ __forceinline__ int16_t wrap_i16(float v) { return (int16_t)(uint16_t)((uint32_t)(int32_t)v & 0xffffu); }
+__device__ __forceinline__ int16_t wrap_i16(float v) { return mpc_wrap_i16(v); }
 
 __global__ void renorm_cast_kernel(const float *__restrict__ cdf, int64_t n, int L, float factor, int order,
                                    int16_t *__restrict__ out) {
@@ -109,12 +108,7 @@ __global__ void bits_lut_kernel(const float *__restrict__ table_f, int K, int M,
     lut[o] = code_length(__fsub_rn(row[s + 1], row[s]), form);
 }
 
-// torch.distributions.Laplace(0, scale).cdf(x) = 0.5 - 0.5 * sign(x) * expm1(-|x| / scale)
-__device__ __forceinline__ float laplace_cdf(float x, float scale) {
-    float sg = (x > 0.0f) ? 0.5f : ((x < 0.0f) ? -0.5f : 0.0f);
-    float em = (float)expm1((double)__fdiv_rn(-fabsf(x), scale));
-    return __fsub_rn(0.5f, __fmul_rn(sg, em));
-}
+__device__ __forceinline__ float laplace_cdf(float x, float scale) { return mpc_laplace_cdf(x, scale); }
 
 __global__ void laplace_bits_kernel(const float *__restrict__ y, const float *__restrict__ sigma, int64_t n,
                                     float *__restrict__ bits, double *__restrict__ total) {
@@ -218,23 +212,31 @@ __global__ void laplace_rows_kernel(const float *__restrict__ sigma, int64_t n, 
     if (i >= n * L) return;
     int64_t e = i / L;
     int s = (int)(i % L);
-    float sc = fminf(fmaxf(sigma[e], 1e-10f), 1e10f);
-    float c = laplace_cdf(first + (float)s, sc);
-    out[i] = wrap_i16(rintf(__fadd_rn(__fmul_rn(c, factor), (float)s)));
+    out[i] = (int16_t)(uint16_t)mpc_laplace_row_entry(mpc_laplace_scale(sigma[e]), first, s, factor);
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)mpc_cdiv(n, 256); }
 
 }  // namespace
 
-static int make_prep(mpc_ctx *ctx, const float *const params[11], int64_t n_rows, float **prep_out) {
+// The prepared parameter image of one call: stream-ordered memory that is given back on every way out of the entry
+// point, the error returns included.
+struct PrepBuffer {
+    float *ptr = nullptr;
+    hipStream_t stream = nullptr;
+    ~PrepBuffer() {
+        if (ptr) (void)hipFreeAsync(ptr, stream);
+    }
+};
+
+static int make_prep(mpc_ctx *ctx, const float *const params[11], int64_t n_rows, PrepBuffer &prep) {
     for (int i = 0; i < 11; ++i) MPC_REQUIRE(ctx, params[i] != nullptr, "bitparm: params[%d] is NULL", i);
-    float *prep = nullptr;
-    MPC_HIP(ctx, hipMallocAsync((void **)&prep, sizeof(float) * PREP * n_rows, ctx->stream));
+    prep.stream = ctx->stream;
+    MPC_HIP(ctx, hipMallocAsync((void **)&prep.ptr, sizeof(float) * PREP * n_rows, ctx->stream));
     bitparm_prepare_kernel<<<dim3(blocks_for(n_rows)), dim3(256), 0, ctx->stream>>>(
         params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8],
-        params[9], params[10], n_rows, prep);
-    *prep_out = prep;
+        params[9], params[10], n_rows, prep.ptr);
+    MPC_CHECK_LAUNCH(ctx, "bitparm_prepare");
     return MPC_OK;
 }
 
@@ -244,12 +246,11 @@ int mpc_bitparm_cdf_table(mpc_ctx *ctx, const float *const params[11], int64_t n
                           int L, float *table_f) {
     MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, params && table_f && n_rows > 0 && L > 1, "bitparm_cdf_table: bad arguments");
-    float *prep = nullptr;
-    int rc = make_prep(ctx, params, n_rows, &prep);
+    PrepBuffer prep;
+    int rc = make_prep(ctx, params, n_rows, prep);
     if (rc) return rc;
-    bitparm_table_kernel<<<dim3(blocks_for(n_rows * L)), dim3(256), 0, ctx->stream>>>(prep, n_rows, first_target, L, table_f);
+    bitparm_table_kernel<<<dim3(blocks_for(n_rows * L)), dim3(256), 0, ctx->stream>>>(prep.ptr, n_rows, first_target, L, table_f);
     MPC_CHECK_LAUNCH(ctx, "bitparm_table");
-    MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
     return MPC_OK;
 }
 
@@ -257,12 +258,11 @@ int mpc_bitparm_cdf_eval(mpc_ctx *ctx, const float *const params[11], int64_t n_
                          int64_t n_per_row, int row_minor, float offset, float *out) {
     MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, params && x && out && n_rows > 0 && n_per_row > 0, "bitparm_cdf_eval: bad arguments");
-    float *prep = nullptr;
-    int rc = make_prep(ctx, params, n_rows, &prep);
+    PrepBuffer prep;
+    int rc = make_prep(ctx, params, n_rows, prep);
     if (rc) return rc;
-    bitparm_eval_kernel<<<dim3(blocks_for(n_rows * n_per_row)), dim3(256), 0, ctx->stream>>>(prep, n_rows, x, n_per_row, row_minor, offset, out);
+    bitparm_eval_kernel<<<dim3(blocks_for(n_rows * n_per_row)), dim3(256), 0, ctx->stream>>>(prep.ptr, n_rows, x, n_per_row, row_minor, offset, out);
     MPC_CHECK_LAUNCH(ctx, "bitparm_eval");
-    MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
     return MPC_OK;
 }
 
@@ -271,13 +271,12 @@ int mpc_prior_bits_network(mpc_ctx *ctx, const float *const params[11], int K, i
     MPC_ENTER(ctx);
     MPC_REQUIRE(ctx, params && y && n_loc > 0 && M > 0 && K > 0 && K <= 64 && (total_bits || idx || minbits),
                 "prior_bits_network: bad arguments (K must be 64 or less)");
-    float *prep = nullptr;
-    int rc = make_prep(ctx, params, (int64_t)K * M, &prep);
+    PrepBuffer prep;
+    int rc = make_prep(ctx, params, (int64_t)K * M, prep);
     if (rc) return rc;
-    prior_bits_network_kernel<<<dim3((unsigned)mpc_cdiv(n_loc, 4)), dim3(256), 0, ctx->stream>>>(prep, K, M, y, noise, n_loc, y_entropy,
+    prior_bits_network_kernel<<<dim3((unsigned)mpc_cdiv(n_loc, 4)), dim3(256), 0, ctx->stream>>>(prep.ptr, K, M, y, noise, n_loc, y_entropy,
                                                                                                  total_bits, idx, minbits);
     MPC_CHECK_LAUNCH(ctx, "prior_bits_network");
-    MPC_HIP(ctx, hipFreeAsync(prep, ctx->stream));
     return MPC_OK;
 }
 

@@ -74,3 +74,26 @@ struct mpc_device_guard {
 constexpr int MPC_MAX_DEVICES = 64;     // per-device flags (kernel attributes set, static scratch addresses)
 
 static inline int64_t mpc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device functions shared by the table kernels (entropy_tables.hip) and the coder (rans.hip) -------------------
+// float -> int16 the way a vectorised x86 cast does it: through int32, keeping the low 16 bits.
+__device__ __forceinline__ int16_t mpc_wrap_i16(float v) { return (int16_t)(uint16_t)((uint32_t)(int32_t)v & 0xffffu); }
+
+// torch.distributions.Laplace(0, scale).cdf(x) = 0.5 - 0.5 * sign(x) * expm1(-|x| / scale)
+__device__ __forceinline__ float mpc_laplace_cdf(float x, float scale) {
+    float sg = (x > 0.0f) ? 0.5f : ((x < 0.0f) ? -0.5f : 0.0f);
+    float em = (float)expm1((double)__fdiv_rn(-fabsf(x), scale));
+    return __fsub_rn(0.5f, __fmul_rn(sg, em));
+}
+
+// sigma.clamp(1e-10, 1e10) of abstract_model.py:405 (a NaN becomes the lower bound)
+__device__ __forceinline__ float mpc_laplace_scale(float sigma) { return fminf(fmaxf(sigma, 1e-10f), 1e10f); }
+
+// Entry s of the int16 CDF row of Laplace(0, scale) at the targets first + s, "add arange, then round" order
+// (abstract_model.py:59-73 applied to :409-416), as the unsigned 16-bit value the coder compares with: the ONE
+// definition of a row entry, used by the kernel that materialises rows and by both sides of the coder that does not,
+// so that encoder and decoder see the same integers.  factor = 2^precision - (L - 1).
+__device__ __forceinline__ uint32_t mpc_laplace_row_entry(float scale, float first, int s, float factor) {
+    const float c = mpc_laplace_cdf(first + (float)s, scale);
+    return (uint32_t)(uint16_t)mpc_wrap_i16(rintf(__fadd_rn(__fmul_rn(c, factor), (float)s)));
+}

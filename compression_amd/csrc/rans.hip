@@ -122,6 +122,32 @@ __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const ui
     params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = start | (freq << 16);
 }
 
+// symbol_params for per-element Laplace(0, sigma) rows (the hyperprior's main stream, abstract_model.py:402-423): the
+// two row entries a symbol needs are evaluated from its sigma; no row is ever stored.  sigma is laid out like sym,
+// [n_images][n_loc][M].
+__global__ __launch_bounds__(256) void symbol_params_laplace_kernel(Geometry g, const float *__restrict__ sigma, float first,
+                                                                     float factor, const int16_t *__restrict__ sym,
+                                                                     uint32_t *__restrict__ params,
+                                                                     int32_t *__restrict__ status) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)g.n_images * g.n_symbols;
+    if (i >= total) return;
+    int img = (int)(i / g.n_symbols);
+    uint32_t local = (uint32_t)(i % g.n_symbols);
+    int s = sym[i];
+    bool bad = (s < 0) | (s > g.L - 2);
+    s = bad ? 0 : s;
+    const float scale = mpc_laplace_scale(sigma[i]);
+    uint32_t start = mpc_laplace_row_entry(scale, first, s, factor);
+    uint32_t end = (s == g.L - 2) ? 0x10000u : mpc_laplace_row_entry(scale, first, s + 1, factor);
+    if (end <= start) bad = true;
+    uint32_t freq = bad ? 1u : end - start;
+    if (bad) { start = 0; atomicMin(&status[img], -10); }
+    uint32_t stream = local / g.sps, r = local % g.sps;
+    int64_t G = (int64_t)g.n_images * g.n_streams;
+    params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = start | (freq << 16);
+}
+
 __global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const uint32_t *__restrict__ params,
                                                              uint16_t *__restrict__ scratch,
                                                              uint32_t *__restrict__ lens, const int32_t *__restrict__ ov) {
@@ -343,6 +369,104 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
             if (t == 0) dst[i] = decoded_value(g, (int)s);
         }
         if (err) break;
+    }
+    if (!err && (x != RANS_L || wp != wend)) err = -26;
+    if (err && t == 0) atomicMin(&status[img], err);
+}
+
+// Decoder for per-element Laplace(0, sigma) rows, S = L - 1 <= 256 symbols.  Nothing is read per symbol but its sigma
+// (4 bytes, fetched 16 symbols at a time, one block ahead): the 16-lane group of a stream finds the symbol with the
+// two-level search of the fast decoder below, evaluating the row entries it looks at -- lane t the segment head
+// entry(16 t), computed a symbol ahead because it depends on sigma only, then entry(16 seg + t) of the segment the
+// state falls into.  Entries at index >= S count as 2^16, as in count_le.  The entries come from
+// mpc_laplace_row_entry, the function the encoder side uses, so both sides see the same integers.
+__global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g, const float *__restrict__ sigma, float first,
+                                                                      float factor, const uint8_t *__restrict__ in,
+                                                                      size_t in_stride, const uint64_t *__restrict__ nbytes,
+                                                                      int16_t *__restrict__ sym_out,
+                                                                      int32_t *__restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int t = lane & (GROUP - 1);
+    const int gshift = lane & ~(GROUP - 1);
+    const int64_t gid = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    if (gid >= G) return;                                   // whole groups leave together
+    const int img = (int)(gid / g.n_streams);
+    const uint32_t stream = (uint32_t)(gid % g.n_streams);
+    const uint8_t *src = in + (size_t)img * in_stride;
+    const uint64_t nb = nbytes[img];
+    const uint64_t hdr = 16 + 2 * (uint64_t)g.n_streams;   // the host has checked hdr <= in_stride < 2^32
+    int err = 0;
+    if (nb < hdr || nb > in_stride) err = -20;
+    uint32_t my_len = 0, off = (uint32_t)hdr;
+    if (!err) {
+        const uint32_t *h4 = (const uint32_t *)src;
+        if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
+    }
+    if (!err) {
+        const uint16_t *lens = (const uint16_t *)(src + 16);
+        uint32_t acc = 0;
+        for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
+        off += 2 * group_sum(acc);
+        my_len = lens[stream];
+        if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
+    }
+    if (err) {
+        if (t == 0) atomicMin(&status[img], err);
+        return;
+    }
+    const uint16_t *words = (const uint16_t *)(src + off);
+    const uint16_t *wend = words + my_len;
+    uint32_t x = (uint32_t)words[0] | ((uint32_t)words[1] << 16);
+    const uint16_t *wp = words + 2;
+    uint32_t wnext = (wp < wend) ? *wp : 0;                 // next renormalisation word, loaded ahead
+
+    const uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
+    const uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
+    const uint32_t len = e - b;
+    const int S = g.L - 1;
+    const float *sg = sigma + (int64_t)img * g.n_symbols + b;
+    int16_t *dst = sym_out + (int64_t)img * g.n_symbols + b;
+    auto entry = [&](float scale, int s) -> uint32_t { return s < S ? mpc_laplace_row_entry(scale, first, s, factor) : 0x10000u; };
+    auto block_scale = [&](uint32_t first_sym) { return first_sym + t < len ? mpc_laplace_scale(sg[first_sym + t]) : 1.0f; };
+
+    float scales = block_scale(0), scales_nx = 1.0f;        // lane t: symbols 16 q + t of the current / next block
+    uint32_t heads = entry(__shfl(scales, 0, GROUP), 16 * t);
+    uint32_t mysym = 0;
+    for (uint32_t n = 0; n < len; ++n) {
+        const int q = (int)(n & 15);
+        if (q == 0) scales_nx = block_scale(n + 16);
+        const float scale = __shfl(scales, q, GROUP);
+        // the next symbol's segment heads: off the chain of the coder state
+        const float scale_nx = q == 15 ? __shfl(scales_nx, 0, GROUP) : __shfl(scales, (q + 1) & 15, GROUP);
+        const uint32_t heads_nx = entry(scale_nx, 16 * t);
+        // ---- the chain: state -> segment -> entry -> new state ----
+        const uint32_t slot = x & 0xffffu;
+        const uint32_t seg_cnt = __popc((uint32_t)(__ballot(heads <= slot) >> gshift) & 0xffffu);
+        const int seg = seg_cnt ? (int)seg_cnt - 1 : 0;
+        const uint32_t ent = entry(scale, 16 * seg + t);
+        const uint32_t in_seg = __popc((uint32_t)(__ballot(ent <= slot) >> gshift) & 0xffffu);
+        if (seg_cnt == 0 || in_seg == 0) { err = -24; break; }          // slot below the row's first entry: corrupt stream
+        const int s = 16 * seg + (int)in_seg - 1;
+        const uint32_t start = (uint32_t)__shfl((int)ent, (int)in_seg - 1, GROUP);
+        const uint32_t end_in = (uint32_t)__shfl((int)ent, (int)in_seg & 15, GROUP);
+        const uint32_t end_hd = (uint32_t)__shfl((int)heads, (seg + 1) & 15, GROUP);
+        const uint32_t end = in_seg < 16 ? end_in : (seg == 15 ? 0x10000u : end_hd);
+        x = (end - start) * (x >> 16) + slot - start;
+        if (x < RANS_L) {
+            if (wp >= wend) { err = -25; break; }
+            x = (x << 16) | wnext;
+            ++wp;
+            wnext = (wp < wend) ? *wp : 0;
+        }
+        // ---- off the chain: symbols are written 16 at a time, one per lane ----
+        if (t == q) mysym = (uint32_t)s;
+        if (q == 15 || n + 1 == len) {
+            const uint32_t firstn = n & ~15u;
+            if (firstn + t <= n) dst[firstn + t] = decoded_value(g, (int)mysym);
+        }
+        heads = heads_nx;
+        if (q == 15) scales = scales_nx;
     }
     if (!err && (x != RANS_L || wp != wend)) err = -26;
     if (err && t == 0) atomicMin(&status[img], err);
@@ -846,6 +970,63 @@ int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, in
     MPC_REQUIRE(ctx, aligned != nullptr, "rans_decode_noalloc: the static scratch of device %d was not initialised", ctx->device);
     // align_rows_kernel rewrites every byte of the K*M rows this call reads, so the previous call's contents never show
     return rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+}
+
+}  // extern "C"
+
+// ---- per-element Laplace rows: the hyperprior's main stream without materialised rows ---------------------------------
+extern "C" {
+
+int mpc_rans_encode_laplace(mpc_ctx *ctx, const float *sigma, const int16_t *sym, float first_target, int L, int precision,
+                            int n_images, int64_t n_loc, int M, int n_streams, int locs_per_stream, void *workspace,
+                            size_t workspace_bytes, uint8_t *out, size_t out_stride, uint64_t *nbytes_dev,
+                            int32_t *status_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, sigma && sym && workspace && out && nbytes_dev && status_dev, "rans_encode_laplace: NULL argument");
+    MPC_REQUIRE(ctx, L > 1 && L <= 257 && precision >= 8 && precision <= 16, "rans_encode_laplace: L must be 2..257, precision 8..16");
+    Geometry g;
+    int rc = check_geometry(ctx, g, 1, M, L, n_images, n_loc, n_streams, locs_per_stream);
+    if (rc) return rc;
+    MPC_REQUIRE(ctx, locs_per_stream == (int)mpc_cdiv(n_loc, n_streams), "rans_encode_laplace: locs_per_stream must be ceil(n_loc / n_streams)");
+    MPC_REQUIRE(ctx, ((uintptr_t)out % 4) == 0 && out_stride % 4 == 0 && ((uintptr_t)workspace % 256) == 0,
+                "rans_encode_laplace: out must be 4-byte aligned with a stride multiple of 4; workspace 256-byte aligned");
+    Workspace w = carve(workspace, n_images, n_loc, M, n_streams, locs_per_stream);
+    if (w.bytes > workspace_bytes) MPC_FAIL(ctx, MPC_ENOMEM, "rans_encode_laplace: workspace too small (%zu < %zu)", workspace_bytes, w.bytes);
+    MPC_REQUIRE(ctx, out_stride >= 16 + 2 * (size_t)n_streams, "rans_encode_laplace: out_stride smaller than the header");
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    const int64_t total = (int64_t)g.n_images * g.n_symbols;
+    MPC_REQUIRE(ctx, mpc_cdiv(total, 256) < (1ll << 31), "rans_encode_laplace: too many symbols in one call");
+    const float factor = (float)(1 << precision) - (float)(L - 1);
+    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
+    symbol_params_laplace_kernel<<<dim3((unsigned)mpc_cdiv(total, 256)), dim3(256), 0, ctx->stream>>>(g, sigma, first_target, factor, sym,
+                                                                                                   w.params, status_dev);
+    MPC_CHECK_LAUNCH(ctx, "rans symbol_params_laplace");
+    encode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, 64)), dim3(64), 0, ctx->stream>>>(g, w.params, w.scratch, w.lens, nullptr);
+    MPC_CHECK_LAUNCH(ctx, "rans encode_streams");
+    header_kernel<<<dim3((unsigned)g.n_images), dim3(256), 0, ctx->stream>>>(g, w.lens, w.offs, out, out_stride, nbytes_dev, status_dev, nullptr);
+    MPC_CHECK_LAUNCH(ctx, "rans header");
+    copy_streams_kernel<<<dim3((unsigned)G), dim3(256), 0, ctx->stream>>>(g, w.scratch, w.lens, w.offs, out, out_stride, nbytes_dev, nullptr);
+    MPC_CHECK_LAUNCH(ctx, "rans copy_streams");
+    return MPC_OK;
+}
+
+int mpc_rans_decode_laplace(mpc_ctx *ctx, const float *sigma, float first_target, int L, int precision, const uint8_t *in,
+                            size_t in_stride, const uint64_t *nbytes_dev, int n_images, int64_t n_loc, int M, int n_streams,
+                            int locs_per_stream, int16_t *sym_out, int32_t *status_dev) {
+    MPC_ENTER(ctx);
+    MPC_REQUIRE(ctx, sigma != nullptr, "rans_decode_laplace: NULL argument");
+    MPC_REQUIRE(ctx, L > 1 && L <= 257 && precision >= 8 && precision <= 16, "rans_decode_laplace: L must be 2..257, precision 8..16");
+    Geometry g;
+    int rc = rans_decode_check(ctx, g, (const int16_t *)sigma, 1, M, L, (const int32_t *)sigma, in, in_stride, nbytes_dev, n_images,
+                               n_loc, n_streams, locs_per_stream, sym_out, status_dev);
+    if (rc) return rc;
+    const int64_t G = (int64_t)g.n_images * g.n_streams;
+    const float factor = (float)(1 << precision) - (float)(L - 1);
+    MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
+    decode_streams_laplace_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
+        g, sigma, first_target, factor, in, in_stride, nbytes_dev, sym_out, status_dev);
+    MPC_CHECK_LAUNCH(ctx, "rans decode_streams_laplace");
+    return MPC_OK;
 }
 
 }  // extern "C"

@@ -530,6 +530,81 @@ def rans_decode_from_bytes(table: torch.Tensor, idx: torch.Tensor, streams: List
     return sym
 
 
+# ---- coder over per-element Laplace rows (never materialised) ---------------------------------------
+def _upload_containers(streams: Sequence[bytes], dev):
+    """Byte strings -> (uint8 [B, stride] on the device, their lengths as int64 on the device)."""
+    import numpy as np
+    stride = (max(len(s) for s in streams) + 3) // 4 * 4
+    host = np.zeros((len(streams), stride), np.uint8)
+    for i, s in enumerate(streams):
+        host[i, :len(s)] = np.frombuffer(s, np.uint8)
+    return torch.from_numpy(host).to(dev), torch.tensor([len(s) for s in streams], dtype=torch.int64, device=dev)
+
+
+def rans_encode_laplace(sigma: torch.Tensor, sym: torch.Tensor, n_images: int, M: int, first_target: float, L: int,
+                        precision: int, n_streams: int, locs_per_stream: int):
+    """sigma fp32 and sym int16, both [n_images, n_loc, M] (NHWC): codes symbol i under the int16 CDF row of
+    Laplace(0, sigma[i]) -- the rows of laplace_cdf_rows, evaluated where they are needed instead of stored.
+    -> (out uint8 [n_images, out_stride], nbytes int64 [n_images], status int32 [n_images])."""
+    _dev(sigma, torch.float32, "sigma"); _dev(sym, torch.int16, "sym")
+    if sigma.numel() != sym.numel() or sym.numel() % (n_images * M):
+        raise MpcError("rans_encode_laplace: sigma and sym must both hold n_images * n_loc * M elements")
+    n_loc = sym.numel() // (n_images * M)
+    out_stride = (MRS1_FIXED_HEADER + n_streams * MRS1_STREAM_OVERHEAD + 2 * n_loc * M + 3) // 4 * 4
+    dev = sym.device
+    ctx = context_for(dev)
+    ws_bytes = ctx.lib.mpc_rans_workspace_bytes(n_images, n_loc, M, n_streams)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((n_images, out_stride), dtype=torch.uint8, device=dev)
+    nbytes = torch.empty(n_images, dtype=torch.int64, device=dev)
+    status = torch.empty(n_images, dtype=torch.int32, device=dev)
+    with _timed("rans_encode_laplace", symbols=n_images * n_loc * M):
+        ctx.call("mpc_rans_encode_laplace", ptr(sigma), ptr(sym), ctypes.c_float(first_target), L, precision, n_images, n_loc, M,
+                 n_streams, locs_per_stream, ptr(ws), ws_bytes, ptr(out), out_stride, ptr(nbytes), ptr(status))
+    return out, nbytes, status
+
+
+def rans_decode_laplace(sigma: torch.Tensor, data: torch.Tensor, nbytes: torch.Tensor, n_images: int, M: int,
+                        first_target: float, L: int, precision: int, n_streams: int, locs_per_stream: int):
+    """Inverse of rans_encode_laplace with the same sigma: -> (sym int16 [n_images, n_loc*M], status int32 [n_images])."""
+    _dev(sigma, torch.float32, "sigma"); _dev(data, torch.uint8, "data"); _dev(nbytes, torch.int64, "nbytes")
+    n_loc = sigma.numel() // (n_images * M)
+    dev = sigma.device
+    sym = torch.empty((n_images, n_loc * M), dtype=torch.int16, device=dev)
+    status = torch.empty(n_images, dtype=torch.int32, device=dev)
+    stride = data.shape[-1] if data.dim() == 2 else data.numel() // n_images
+    with _timed("rans_decode_laplace", symbols=n_images * n_loc * M):
+        context_for(dev).call("mpc_rans_decode_laplace", ptr(sigma), ctypes.c_float(first_target), L, precision, ptr(data), stride,
+                              ptr(nbytes), n_images, n_loc, M, n_streams, locs_per_stream, ptr(sym), ptr(status))
+    return sym, status
+
+
+def rans_encode_laplace_to_bytes(sigma: torch.Tensor, sym: torch.Tensor, n_images: int, M: int, first_target: float, L: int,
+                                 precision: int, est_bytes_per_image: float) -> List[bytes]:
+    n_loc = sym.numel() // (n_images * M)
+    n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image)
+    out, nbytes, status = rans_encode_laplace(sigma, sym, n_images, M, first_target, L, precision, n_streams, lps)
+    meta = torch.cat([nbytes, status.to(torch.int64)]).cpu().tolist()
+    nb, st = meta[:n_images], meta[n_images:]
+    if min(st) < 0:
+        raise MpcError(f"rANS encoder reported {st} (symbol outside the row or zero frequency)")
+    host = out[:, :max(nb)].cpu().numpy()
+    return [host[i, :nb[i]].tobytes() for i in range(n_images)]
+
+
+def rans_decode_laplace_from_bytes(sigma: torch.Tensor, streams: List[bytes], M: int, first_target: float, L: int,
+                                   precision: int) -> torch.Tensor:
+    """-> int16 symbols [n_images, n_loc*M]; the stream geometry is read from the (validated) container headers."""
+    B = len(streams)
+    n_loc = sigma.numel() // (max(B, 1) * M)
+    n_streams, lps = parse_mrs1_headers(streams, n_loc, M)
+    data, nbytes = _upload_containers(streams, sigma.device)
+    sym, status = rans_decode_laplace(sigma, data, nbytes, B, M, first_target, L, precision, n_streams, lps)
+    if int(status.min().item()) < 0:
+        raise MpcError(f"corrupt MRS1 stream: decoder status {status.cpu().tolist()}")
+    return sym
+
+
 # ---- hyperprior likelihoods -----------------------------------------------------------------------
 def laplace_bits_total(yhat: torch.Tensor, sigma: torch.Tensor) -> torch.Tensor:
     _dev(yhat, torch.float32, "yhat"); _dev(sigma, torch.float32, "sigma")

@@ -29,11 +29,10 @@ def test_launcher_starts_one_child_per_gpu_before_any_gpu_call(monkeypatch):
         def __init__(self, cmd, env=None, stdout=None, text=None):
             started.append((cmd, env, stdout))
             self.returncode = 0
+            if stdout is not subprocess.DEVNULL:            # rank 0's output goes to a file of the launcher's
+                stdout.write('{"metric": "x", "n_gpus": 4}\n')
 
-        def communicate(self):
-            return '{"metric": "x", "n_gpus": 4}\n', None
-
-        def wait(self):
+        def wait(self, timeout=None):
             return 0
 
         def poll(self):
@@ -48,7 +47,7 @@ def test_launcher_starts_one_child_per_gpu_before_any_gpu_call(monkeypatch):
     assert all(e["WORLD_SIZE"] == "4" and e["LOCAL_RANK"] == e["RANK"] for _, e, _ in started)
     assert len({e["MASTER_PORT"] for _, e, _ in started}) == 1
     assert all(cmd[1].endswith("bench.py") and cmd[2:] == argv for cmd, _, _ in started)
-    assert started[0][2] == subprocess.PIPE and all(s == subprocess.DEVNULL for _, _, s in started[1:])
+    assert started[0][2] is not subprocess.DEVNULL and all(s == subprocess.DEVNULL for _, _, s in started[1:])
     assert not torch.cuda.is_initialized()                  # the parent has not touched a GPU
 
 
@@ -77,6 +76,42 @@ def test_two_rank_dry_run_reduces_the_real_statistics():
     for k, v in want.items():
         assert line["stats"][k] == pytest.approx(v, rel=1e-12), k
     assert line["stats"]["images"] == 6
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_job():
+    """Rank 1 exits with an error before it joins the process group; rank 0 would wait in the rendezvous for ever.  The
+    launcher polls all ranks, ends the survivors at the first failure and returns the failing rank's code."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--fail-rank", "1",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert "rank exit codes" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert time.monotonic() - t0 < 60
+
+
+def test_ranks_that_never_finish_are_ended_at_the_deadline(monkeypatch):
+    killed = []
+
+    class Hung:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            self.returncode = None
+
+        def poll(self):
+            return self.returncode
+
+        def terminate(self):
+            killed.append(self)
+            self.returncode = -15
+
+        def wait(self, timeout=None):
+            return self.returncode
+
+    monkeypatch.setattr(bench.subprocess, "Popen", Hung)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.main(["--gpus", "2", "--dry-run", "--launch-timeout", "0.2"]) == 1
+    assert len(killed) == 2
 
 
 def test_counter_table_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):

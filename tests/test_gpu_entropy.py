@@ -259,3 +259,52 @@ def test_laplace_bits_and_rows(dev, ops):
     d = (rows_got.int() - rows_want.int()).abs()
     print(f"laplace rows: {(d != 0).float().mean().item():.2e} entries differ")
     assert d.max().item() <= 1 and (d != 0).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize("Lrow,Mch,n_img,n_loc,n_streams", [(257, 32, 2, 96, 5), (257, 8, 1, 40, 1), (200, 16, 3, 33, 4)])
+def test_laplace_coder_equals_the_coder_over_materialised_rows(dev, ops, Lrow, Mch, n_img, n_loc, n_streams):
+    """The coder that evaluates the per-element Laplace(0, sigma) rows where it needs them (mpc_rans_encode_laplace /
+    mpc_rans_decode_laplace) against the coder run over the same rows materialised as a [n_img*n_loc, M, L] table with
+    one "prior" per location (what the reference hands to torchac, abstract_model.py:409-423): the containers are the
+    same bytes, both decoders return the coded symbols.  Ragged cases: a row shorter than 257, a last stream that is
+    shorter than the others, one stream only, scales from 1e-3 (all mass on one symbol) to 60."""
+    g = torch.Generator().manual_seed(Lrow + n_loc)
+    n = n_img * n_loc * Mch
+    sigma = torch.exp(torch.rand(n, generator=g) * 11.0 - 6.9)
+    sigma[::97] = 0.0                                       # clamped to 1e-10: a step function
+    S = Lrow - 1
+    centre = S // 2 - 1                                     # symbol of the value 0; targets first + s are the bin edges,
+    first = -centre - 0.5                                   # as in the model (min_feat - 0.5 with min_feat = -127)
+    y = torch.round(torch.randn(n, generator=g) * sigma.clamp(max=40.0))
+    sym = (y + centre).clamp(0, S - 1).to(torch.int16)
+    sym[5], sym[6] = 0, S - 1                               # both ends of the row
+    sig_d, sym_d = sigma.to(dev), sym.to(dev)
+    lps = -(-n_loc // n_streams)
+    out, nbytes, status = ops.rans_encode_laplace(sig_d, sym_d, n_img, Mch, first, Lrow, 16, n_streams, lps)
+    assert status.cpu().tolist() == [0] * n_img
+    # the same rows, materialised, through the table coder: one table row set per location of the whole batch
+    rows = ops.laplace_cdf_rows(sig_d, first, Lrow, 16).view(n_img * n_loc, Mch, Lrow)
+    idx = torch.arange(n_img * n_loc, dtype=torch.int32, device=dev)
+    out_t, nbytes_t, status_t = ops.rans_encode(rows, idx, sym_d, n_img, n_streams, lps)
+    assert status_t.cpu().tolist() == [0] * n_img
+    nb = nbytes.cpu().tolist()
+    assert nb == nbytes_t.cpu().tolist()
+    for i in range(n_img):
+        assert torch.equal(out[i, :nb[i]], out_t[i, :nb[i]])
+    got, st = ops.rans_decode_laplace(sig_d, out, nbytes, n_img, Mch, first, Lrow, 16, n_streams, lps)
+    assert st.cpu().tolist() == [0] * n_img and torch.equal(got.view(-1), sym_d)
+    got_t, st_t = ops.rans_decode(rows, idx, out_t, nbytes_t, n_img, n_streams, lps)
+    assert torch.equal(got_t.view(-1), sym_d)
+    # a damaged payload is reported, not decoded silently
+    bad = out.clone()
+    bad[0, 16 + 2 * n_streams + 3] ^= 0x5A
+    _, st_bad = ops.rans_decode_laplace(sig_d, bad, nbytes, n_img, Mch, first, Lrow, 16, n_streams, lps)
+    got_bad, _ = ops.rans_decode_laplace(sig_d, bad, nbytes, n_img, Mch, first, Lrow, 16, n_streams, lps)
+    assert st_bad.cpu()[0].item() < 0 or not torch.equal(got_bad.view(-1), sym_d)
+    # a symbol outside the row is refused by the encoder
+    sym_bad = sym_d.clone()
+    sym_bad[3] = S
+    _, _, st_enc = ops.rans_encode_laplace(sig_d, sym_bad, n_img, Mch, first, Lrow, 16, n_streams, lps)
+    assert st_enc.cpu()[0].item() == -10
+    with pytest.raises(Exception, match="257"):
+        ops.rans_encode_laplace(sig_d, sym_d, n_img, Mch, first, 300, 16, n_streams, lps)

@@ -278,6 +278,69 @@ def test_hyperprior_entropy_coded_round_trip(dev, golden):
         m.decode([main[:len(main) // 2], zstr, H, W])
 
 
+def test_hyperprior_batch_round_trip_without_materialised_rows(dev):
+    """encode_batch / decode_batch of the hyperprior model on 3 images: every image's strings equal the one-image
+    encode()'s, the decode reproduces g_s(round(y)) exactly, and the device memory of the coder calls stays at a few
+    bytes per symbol (materialised rows would need 514, twice)."""
+    import compression_amd as ca
+    m = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M, synthesis_precision="fp32")
+    m.load_state_dict(synth.hyperprior_state_dict(236, N, M))
+    m.eval()
+    x = synth.smooth_image(5, 3, 128, 192).to(dev)
+    streams = m.encode_batch(x)
+    recon = m.decode_batch(streams)
+    # the coder's own device memory, measured round the two coder calls with sigma and the symbols in hand: the
+    # encoder's 4-byte (start, frequency) word and 2-byte output word per symbol, the containers, the decoded symbols
+    from compression_amd import ops
+    y, yhat = m.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
+    _, zhat = m.priorEncoder.forward_nhwc(y, round_out=True)
+    sigma = m.priorDecoder.forward_nhwc(zhat)
+    sym_y, _ = ops.latent_to_symbols(yhat, -127, 1, 256)
+    n_sym = sym_y.numel()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats(dev)
+    base = torch.cuda.memory_allocated(dev)
+    mains = ops.rans_encode_laplace_to_bytes(sigma, sym_y, 3, M, -127.5, 257, 16, 3000.0)
+    back = ops.rans_decode_laplace_from_bytes(sigma, mains, M, -127.5, 257, 16)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated(dev) - base
+    print(f"hyperprior main stream: peak device memory of the coder calls {peak / n_sym:.1f} bytes per symbol")
+    assert peak < 20 * n_sym                                # (materialised rows: 514 bytes per symbol, twice)
+    assert torch.equal(back.view(-1), sym_y.view(-1))
+    assert len(streams) == 3 and all(s[2:] == [128, 192] for s in streams)
+    for i in range(3):
+        one = m.encode(x[i:i + 1])
+        assert one[0] == streams[i][0] and one[1] == streams[i][1]
+    yq, _ = m.compress(x)
+    assert torch.equal(recon, m.decode(yq))
+    assert torch.equal(m.decode(streams[1]), recon[1:2])
+    ys, zs = m.encode_batch(x, entropy_coding=False)
+    y1, z1 = m.encode(x[2:3], entropy_coding=False)
+    assert torch.equal(ys[2], y1) and torch.equal(zs[2], z1)
+
+
+def test_testolina_hyperprior_codec_round_trip(dev):
+    """TestolinaHP (hyperprior entropy model + the extended decoder): encode -> bytes -> decode returns exactly what
+    its g_s makes of round(y), and the coded size is close to the model's own estimate."""
+    import compression_amd as ca
+    sdh = synth.transform_weights(237, N, M, testolina=True)
+    sdh.update(synth.hyperprior_weights(239, N, M))
+    m = ca.init_model("TestolinaHP", dev, out_channel_N=N, out_channel_M=M)
+    m.load_state_dict(sdh)
+    m.eval()
+    x = synth.smooth_image(41, 2, 128, 192).to(dev)
+    streams = m.encode_batch(x)
+    recon = m.decode_batch(streams)
+    yq, _ = m.compress(x)
+    assert torch.equal(recon, m.decode(yq))
+    out = m(x)
+    est_bits = float(out["bpp"]) * 2 * 128 * 192
+    coded_bits = 8 * sum(len(s[0]) + len(s[1]) for s in streams)
+    print(f"TestolinaHP: coded {coded_bits} bits, estimated {est_bits:.0f}")
+    assert coded_bits < est_bits * 1.03 + 2 * 8 * 64
+    assert (recon.clamp(0, 1) - out["reconstructed_image"]).abs().max().item() < 1e-6
+
+
 def _lib_error():
     from compression_amd import MpcError
     return (MpcError, ValueError)

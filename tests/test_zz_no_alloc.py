@@ -30,20 +30,36 @@ def _case(seed, n_img, h, w, dev, prior_seed):
 
 def test_noalloc_decode_matches_allocating_decode():
     assert torch.cuda.is_available(), "this test needs the MI355X"
-    from compression_amd import MpcError, ops
+    from compression_amd import MpcError, _lib, ops
+    from compression_amd._lib import ptr
     dev = torch.device("cuda:0")
+    # A context of its own, which has never run an allocating decode: its scratch is empty, so a variant that went
+    # through the context's scratch after all would have to grow it, and that hipMalloc would show below.
+    fresh = _lib.Context(0, torch.cuda.current_stream(dev).cuda_stream)
     for seed, n_img, h, w, prior_seed in ((21, 3, 24, 20, 235), (22, 1, 6, 10, 777)):       # second call: smaller, other table
         table, idx, sym, out, nbytes, n_img, n_streams, lps = _case(seed, n_img, h, w, dev, prior_seed)
-        want, want_st = ops.rans_decode(table, idx, out, nbytes, n_img, n_streams, lps)
         got = torch.full((n_img, h * w * M), -1, dtype=torch.int16, device=dev)
         got_st = torch.full((n_img,), 99, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        before = torch.cuda.memory_allocated(dev)
-        ops.rans_decode_noalloc(table, idx, out, nbytes, n_img, n_streams, lps, got, got_st)
+        # free device memory as the driver sees it (hipMemGetInfo): covers hipMalloc calls inside the library, which
+        # torch's own counters do not see
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        torch_before = torch.cuda.memory_allocated(dev)
+        Kt, Mt, Lt = table.shape
+        fresh.call("mpc_rans_decode_noalloc", ptr(table), Kt, Mt, Lt, ptr(idx), ptr(out), out.shape[-1], ptr(nbytes),
+                   n_img, h * w, n_streams, lps, ptr(got), ptr(got_st))
         torch.cuda.synchronize()
-        assert torch.cuda.memory_allocated(dev) == before
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
+        assert torch.cuda.memory_allocated(dev) == torch_before
+        # the allocating entry point, afterwards, for the comparison
+        want, want_st = ops.rans_decode(table, idx, out, nbytes, n_img, n_streams, lps)
         assert got_st.cpu().tolist() == want_st.cpu().tolist() == [0] * n_img
         assert torch.equal(got, want) and torch.equal(got.view(-1), sym)
+        # and through the wrapper on the shared context
+        got.fill_(-1)
+        ops.rans_decode_noalloc(table, idx, out, nbytes, n_img, n_streams, lps, got, got_st)
+        assert torch.equal(got, want)
+    fresh.close()
     # beyond the static scratch: refused with a clear error, nothing launched
     big = torch.zeros((K + 1, M, 257), dtype=torch.int16, device=dev)
     with pytest.raises(MpcError, match="static scratch"):
