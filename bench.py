@@ -9,6 +9,8 @@ Workloads (--config, default 3 = the configuration the encode+decode metric is q
     3  full codec on 24 x 768x512 per GPU                                         encode+decode MP/s
     4  full codec on one 3840x2160 image per GPU per step                         encode+decode MP/s
     5  JDC: ManyPriors_DC (or --arch TestolinaManyPriors) on 8 noisy 1024x1024 per GPU, full codec
+    6  hyperprior codec: TestolinaHP (or --arch Balle2018PTTFExp) on 8 x 768x512 per GPU, full codec (not a BASELINE
+       configuration: the reference's hyperprior encode/decode path, abstract_model.py:370-500)
 One codec STEP =
     encode:  g_a -> round -> symbols -> prior competition -> MRS1 rANS -> byte strings on the host
     decode:  byte strings -> rANS decode -> latent -> g_s -> clamp -> x_hat on the device
@@ -63,12 +65,17 @@ CONFIGS = {
             what="full codec on one 3840x2160 image"),
     5: dict(arch="ManyPriors_DC", batch=8, height=1024, width=1024, mode="codec", data="noisy",
             what="JDC full codec on 8 noisy 1024x1024 images"),
+    6: dict(arch="TestolinaHP", batch=8, height=512, width=768, mode="hp_codec", data="smooth",
+            what="hyperprior full codec (encode_batch -> bytes -> decode_batch, main stream under per-element Laplace rows) "
+                 "on 8 x 768x512 images"),
 }
 # sources whose change invalidates the committed counter passes of the dominant kernel
 TRAFFIC_SOURCES = ("compression_amd/csrc/conv5s2_patch_x3.hip", "compression_amd/csrc/conv_x3_epilogue.h",
                    "compression_amd/csrc/conv_common.h")
-PMC_TABLE = os.path.join(REPO, "profiles", "r2_pmc_counters.csv")
-PMC_META = os.path.join(REPO, "profiles", "r2_pmc_meta.json")
+PMC_TABLE = os.path.join(REPO, "profiles", "r3_pmc_counters.csv")
+PMC_META = os.path.join(REPO, "profiles", "r3_pmc_meta.json")
+NUM_SIMD = 256 * 4               # SIMDs of the chip
+NUM_XCD = 8
 
 
 def kernel_peak(name):
@@ -104,6 +111,26 @@ def pmc_traffic(kernel):
             if kernel in r["Kernel"] and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
                 return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, meta.get("commit")
     return None, meta.get("commit")
+
+
+def pmc_mfma(kernel):
+    """-> {"mfma_busy", "clock_ghz", "profiled_at"} of `kernel` from the committed counter passes, or None: the fraction
+    of the chip's SIMD cycles in which the matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE / 8 XCDs x
+    1024 SIMDs) and the clock the kernel ran at under the counters (GRBM_GUI_ACTIVE / 8 over its duration)."""
+    import csv
+    if not (os.path.exists(PMC_TABLE) and os.path.exists(PMC_META)):
+        return None
+    meta = json.load(open(PMC_META))
+    with open(PMC_TABLE, newline="") as f:
+        for r in csv.DictReader(f):
+            if kernel in r["Kernel"] and r.get("SQ_VALU_MFMA_BUSY_CYCLES") and r.get("GRBM_GUI_ACTIVE"):
+                cyc = float(r["GRBM_GUI_ACTIVE"]) / NUM_XCD
+                if cyc <= 0:
+                    return None
+                return {"mfma_busy": float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (cyc * NUM_SIMD),
+                        "clock_ghz": cyc / float(r["AvgNs"]), "profiled_at": meta.get("commit"),
+                        "same_kernel_sources": meta.get("sources_sha256_16") == sources_digest()}
+    return None
 
 
 def parse(argv=None):
@@ -394,10 +421,17 @@ def run_rank(args):
     from tests import synth
 
     testolina = args.arch.startswith("Testolina")
-    kw = dict(out_channel_N=192, out_channel_M=256, num_distributions=64, analysis_precision=args.analysis_precision,
-              synthesis_precision=args.synthesis_precision)
-    model = ca.init_model("ManyPriors", dev, std_suffix="DC", **kw) if args.arch == "ManyPriors_DC" else ca.init_model(args.arch, dev, **kw)
-    model.load_state_dict(synth.manypriors_state_dict(234, testolina=testolina))
+    if args.mode == "hp_codec":
+        # the hyperprior models: exact f32 analysis (h_a reads the unrounded latent), the default fp16 synthesis
+        model = ca.init_model(args.arch, dev, out_channel_N=192, out_channel_M=256)
+        sd = synth.transform_weights(237, 192, 256, testolina=testolina)
+        sd.update(synth.hyperprior_weights(239, 192, 256))
+        model.load_state_dict(sd)
+    else:
+        kw = dict(out_channel_N=192, out_channel_M=256, num_distributions=64, analysis_precision=args.analysis_precision,
+                  synthesis_precision=args.synthesis_precision)
+        model = ca.init_model("ManyPriors", dev, std_suffix="DC", **kw) if args.arch == "ManyPriors_DC" else ca.init_model(args.arch, dev, **kw)
+        model.load_state_dict(synth.manypriors_state_dict(234, testolina=testolina))
     model.eval()
     x, target = make_inputs(args, rank, dev)
     B, _, H, W = x.shape
@@ -411,6 +445,14 @@ def run_rank(args):
         model.decode_batch_synthesis(job, score_against=target)
         xhat, sse = model.decode_batch_finish(job), job["sse"]
         nbytes = float(sum(len(s) for s in streams))
+        acc.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
+        return xhat
+
+    def hyperprior_codec_step():
+        streams = model.encode_batch(x)                     # [main string, z string, H, W] per image, bytes on the host
+        recon = model.decode_batch(streams)
+        xhat, sse = ops.clamp_sse_per_image(recon, target)
+        nbytes = float(sum(len(s[0]) + len(s[1]) for s in streams))
         acc.add_batch_device(sse, 3 * H * W, bits=8.0 * nbytes, pixels=B * H * W, nbytes=nbytes, seconds=state["seconds"], reset=True)
         return xhat
 
@@ -443,7 +485,7 @@ def run_rank(args):
         from compression_amd.pipeline import CodecPipeline
         pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis)
     fpipe = None
-    if args.mode != "codec" and not args.serial:
+    if args.mode == "forward" and not args.serial:
         from compression_amd.pipeline import ForwardPipeline
         fpipe = ForwardPipeline(model, dev, depth=2)
 
@@ -487,10 +529,12 @@ def run_rank(args):
     def keep_last(new, old):
         return old if new is None else new
 
-    if args.mode != "codec":
-        step = forward_step if args.serial else pipelined_forward_step
+    if args.mode == "hp_codec":
+        step = serial_step = hyperprior_codec_step
+    elif args.mode == "forward":
+        step, serial_step = (forward_step if args.serial else pipelined_forward_step), forward_step
     else:
-        step = serial_codec_step if args.serial else pipelined_codec_step
+        step, serial_step = (serial_codec_step if args.serial else pipelined_codec_step), serial_codec_step
 
     def barrier():
         if dist is not None:
@@ -524,6 +568,7 @@ def run_rank(args):
     gc.freeze()
     barrier()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    ops.profile_mark(dev, 1)                                # (a one-thread kernel: the start of the timed region in a kernel trace)
     t0 = time.perf_counter()
     marks = [t0]
     for _ in range(args.steps):
@@ -535,6 +580,7 @@ def run_rank(args):
     state.get("acc", acc).all_reduce()
     barrier()
     dt = time.perf_counter() - t0
+    ops.profile_mark(dev, 2)                                # ... and its end
     last = state.get("acc", acc).result()                   # (pipelined: the accumulator of the last batch's stream)
     device_allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the timed region
     ops.PROFILER = None
@@ -544,7 +590,7 @@ def run_rank(args):
     aprof = ops.PROFILER = ops.Profiler()
     post_steps = min(args.steps, 20)
     for _ in range(post_steps):
-        (serial_codec_step if args.mode == "codec" else forward_step)()
+        serial_step()
     ops.PROFILER = None
     kern = aprof.summary()
     for v in kern.values():
@@ -600,23 +646,30 @@ def run_rank(args):
         if v["bytes"]:
             e["gb_per_s"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
         kernels[k] = e
-    metric = "encode+decode megapixels/sec" if args.mode == "codec" else "eval forward megapixels/sec"
+    metric = "eval forward megapixels/sec" if args.mode == "forward" else "encode+decode megapixels/sec"
+    busy = pmc_mfma(dom) or {}
     out = {
         "metric": metric, "value": value, "unit": "megapixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "f16x3": "f16 hi/lo split x3 (fp32-grade), f32 accumulate"}[args.analysis_precision]
+        "dtype": {"fp32": "f32", "f16x3": "f16 hi/lo split x3 (fp32-grade), f32 accumulate"}["fp32" if args.mode == "hp_codec" else args.analysis_precision]
                  + " (g_a); " + {"fp32": "f32", "fp16": "f16, f32 accumulate"}[args.synthesis_precision] + " (g_s)",
         "data": "synthetic",
         "config": {"workload": f"config {args.config}: {CONFIGS[args.config]['what']} per GPU, {args.arch} N=192 M=256 K=64, "
                                f"random-init weights with spread priors, {args.data} input",
                    "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
                    "parallelism": f"image-sharded x{world}, statistics all-reduce only",
-                   "batches_in_flight": 2 if (pipe is not None or fpipe is not None) else 1, "warmup_steps_run": n_warm},
+                   "batches_in_flight": 2 if (pipe is not None or fpipe is not None) else 1, "warmup_steps_run": n_warm,
+                   "post_pass_steps": post_steps},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,
                      "mfma_passes_per_product": passes, "issued_tflops": achieved * passes,
-                     "avg_launch_ms": d["ms"] / d["calls"], "launches_per_step": d["calls"] / args.steps},
+                     "avg_launch_ms": d["ms"] / d["calls"], "launches_per_step": d["calls"] / args.steps,
+                     # from the committed counter passes (profiles/): share of the chip's SIMD cycles with the matrix pipe
+                     # busy, and the clock the kernel held while the counters ran
+                     "mfma_busy": busy.get("mfma_busy"), "clock_ghz": busy.get("clock_ghz"),
+                     "mfma_busy_profiled_at": busy.get("profiled_at"),
+                     "mfma_busy_same_kernel_sources": busy.get("same_kernel_sources")},
         "kernels": kernels,
         "stats": stats,
     }
@@ -627,7 +680,7 @@ def run_rank(args):
     out["hbm_ceiling"] = hbm_ceiling(dev)
     out["device_allocs_in_timed_region"] = int(device_allocs)
     out["host_ms_between_steps"] = [round((b - a) * 1e3, 3) for a, b in zip(marks, marks[1:])]
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.mode != "hp_codec":     # (the CPU oracle's codec is the Manypriors one)
         out["cpu_baseline"] = cpu_baseline(args.cpu_images, 512, 768) if args.config == 3 else \
             cpu_baseline(max(2, min(args.cpu_images, int(16 * 393216 / (H * W)) or 2)), H, W)
     print(json.dumps(out))

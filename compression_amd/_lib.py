@@ -42,6 +42,7 @@ SIGNATURES = {
     "mpc_synchronize": (c_int, [c_void_p]),
     "mpc_last_error": (c_char_p, [c_void_p]),
     "mpc_version": (c_char_p, []),
+    "mpc_profile_mark": (c_int, [c_void_p, c_int]),
     "mpc_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mpc_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mpc_latent_to_symbols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),

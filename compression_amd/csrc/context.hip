@@ -339,3 +339,44 @@ int mpc_sum_f32(mpc_ctx *ctx, const float *x, int64_t n, double *out_dev) {
 }
 
 }  // extern "C"
+
+// ---- profiling marks -------------------------------------------------------------------------------------------------
+// A kernel that does nothing but show up, under a name of its own, in a kernel trace: bench.py launches one in front of
+// and one behind its timed region, so that per-kernel statistics can be restricted to the launches in between
+// (tools/region_stats.py).  One thread; its argument keeps the two marks apart.
+__global__ void mpc_profile_mark_kernel(int id, int *sink) {
+    if (sink && id == 0x7fffffff) *sink = id;              // (never true: the argument is used, the kernel is kept)
+}
+
+extern "C" int mpc_profile_mark(mpc_ctx *ctx, int id) {
+    MPC_ENTER(ctx);
+    mpc_profile_mark_kernel<<<dim3(1), dim3(1), 0, ctx->stream>>>(id, nullptr);
+    MPC_CHECK_LAUNCH(ctx, "profile_mark");
+    return MPC_OK;
+}
+
+#ifdef MPC_EXPERIMENT_OCCUPIER
+// Measurement builds only (tools/corun_decoder.py): a kernel with the entropy decoder's footprint (2 waves and `lds_bytes`
+// of LDS per workgroup, 41 registers) that only sleeps, to tell what a co-resident kernel costs a transform by
+// occupying the CU from what it costs by using it.
+__global__ __launch_bounds__(128) void mpc_occupier_kernel(float *sink, int sleeps) {
+    extern __shared__ float4 occ_lds[];
+    float v[40];
+    for (int i = 0; i < 40; ++i) v[i] = (float)(threadIdx.x + i);
+    occ_lds[threadIdx.x] = make_float4(v[0], v[1], v[2], v[3]);
+    for (int s = 0; s < sleeps; ++s) {
+        __builtin_amdgcn_s_sleep(127);
+#pragma unroll
+        for (int i = 0; i < 40; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(v[i]));
+    }
+    float t = 0.f;
+    for (int i = 0; i < 40; ++i) t += v[i];
+    if (t == 12345.678f) sink[0] = t + occ_lds[0].x;
+}
+extern "C" int mpc_experiment_occupier(mpc_ctx *ctx, int workgroups, int lds_bytes, int sleeps, float *sink) {
+    MPC_ENTER(ctx);
+    mpc_occupier_kernel<<<dim3(workgroups), dim3(128), lds_bytes, ctx->stream>>>(sink, sleeps);
+    MPC_CHECK_LAUNCH(ctx, "occupier");
+    return MPC_OK;
+}
+#endif

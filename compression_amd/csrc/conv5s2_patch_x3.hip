@@ -263,6 +263,7 @@ int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
     constexpr int NW = TR / 2;
     size_t lds = ((size_t)(2 * TR + 3) * ROW_F4 + 3 * (size_t)NF * 32 * 4) * sizeof(float4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    lds = patch_kernel_lds(lds);
     auto kern = conv5s2_patch_x3_kernel<NF, EPI, TR>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
     bool &attr_done = attr_set[ctx->device];
@@ -281,32 +282,55 @@ int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // First layer (3 -> COUT, 5x5 stride 2, fused GDN) in the same style.  Its K axis is short (k = tap*4 + c over the
-// image padded to 4 channels: 25 taps -> 8 k-steps, then 2 NF k-steps of the GDN mix), so a workgroup lives for only
-// 8 + 2 NF steps and what matters is that nothing in them waits: the whole 35 x 19 image patch of the 16 x 8 output
-// tile is split into fp16 hi/lo ONCE, when it is staged ([hi x4 | lo x4] = one 16-byte slot per pixel, column
-// parities apart so that the 16 lanes of a tile row read consecutive slots), the weights and gamma stream through
-// the LDS-DMA ring, and two workgroups share a CU so that one's prologue and 768-byte-per-pixel stores overlap the
-// other's MFMAs.  A lane's 8 k-values of a k-step are two whole pixels: taps 4S + 2h and 4S + 2h + 1.
+// image padded to 4 channels: 25 taps -> 8 k-steps, then the GDN mix), so a workgroup lives for only 8 + 2 NF steps and
+// what matters is that nothing in them waits: the whole 35 x 19 image patch of the 16 x 8 output tile is split into
+// fp16 hi/lo ONCE, when it is staged ([hi x4 | lo x4] = one 16-byte slot per pixel, column parities apart so that the
+// 16 lanes of a tile row read consecutive slots), the weights and gamma stream through the LDS-DMA ring, and two
+// workgroups share a CU so that one's prologue and 768-byte-per-pixel stores overlap the other's MFMAs.  A lane's
+// 8 k-values of a k-step are two whole pixels: taps 4S + 2h and 4S + 2h + 1.
+//
+// The GDN mix runs in TWO PASSES over the channel axis, each for one half of the output channels (NF/2 tiles): a pass
+// is NF steps of two k-steps x NF/2 output tiles (the same 3 NF MFMAs and the same 12 KB of gamma per step as one
+// k-step x NF tiles would be), after which that half is normalised and stored.  So the wave holds NF/2 norm tiles
+// instead of NF: 6 x 16 accumulators + 3 x 16 norms + operands fit 208 registers instead of 248.  For one output tile
+// the MFMAs are the ones of the single-pass order, in that order: same bits.  The squares (B operands) are formed once
+// per pass.  A pass's chunk is gathered from the k-step-major gamma image by the LDS-DMA's per-lane source addresses.
+//
+// LDS: [patch | ring slot 0 | slot 1 | slot 2 | beta].  The transposing store of a pass (one tile = 128 bytes per pixel
+// at a time, 4 waves x 4 864 bytes) lies over the patch and ring slot 0: the patch is dead after the tap steps, and
+// the ring is started so that the last step of the FIRST pass reads slot 0 -- the slot that no transfer targets until
+// the next step issues one, which a barrier behind the store holds back.
 constexpr int RGB_X2 = 18;                          // slots per column parity
 constexpr int RGB_ROW = 2 * RGB_X2;                 // 36 slots per patch row
 constexpr int RGB_TR = 8, RGB_PR = 2 * RGB_TR + 3;  // 8 tile rows, 19 patch rows
 constexpr int RGB_PATCH = 704;                      // 19 x 36 = 684 slots, rounded up
+constexpr int TS1_ROW_BYTES = 128;                  // one 32-channel tile of a pixel (fp32 or the S16 format: 4 bytes per element)
+constexpr int TS1_ROW_PAD = 144;                    // LDS row pitch (odd multiple of 16 bytes: conflict-free b128)
+constexpr int TS1_WAVE_BYTES = 32 * TS1_ROW_PAD + 32 * 8;
 
 __host__ __device__ constexpr int rgb_tap_slot(int tap) {       // slot offset of a tap inside the patch (taps past 24: weights are zero)
     const int t = tap > 24 ? 24 : tap;
     return (t / 5) * RGB_ROW + ((t % 5) & 1) * RGB_X2 + ((t % 5) >> 1);
 }
 
+// Register budget: 208 (the attribute counts the unified 512-entry file in halves); without the cap the compiler spends
+// the whole 256 that two workgroups per CU would allow on hoisted loads.
 template <int NF>
-__global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params p) {
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(104))) void conv1_rgb_patch_x3_kernel(const Params p) {
     constexpr int NW = 4, NT = 64 * NW, COUT = NF * 32;
-    constexpr int WCH_F4 = COUT * 4;                     // slots of a half chunk (one k-step): [h][hi|lo][cout]
+    constexpr int HF = NF / 2, HOUT = HF * 32;           // output tiles / channels of one GDN pass
+    constexpr int WCH_F4 = COUT * 4;                     // slots of a chunk: one k-step [h][hi|lo][cout], or two k-steps x half the outputs
     constexpr int WPW = WCH_F4 / 64 / NW;
     constexpr int KSTEPS = 8;                            // 25 taps x 4 channels = 100 -> 128 = 8 x 16
-    static_assert(WPW * NW * 64 == WCH_F4, "a half chunk must split evenly into 1 KB pieces per wave");
+    constexpr int NSTEPS = KSTEPS + 2 * NF;              // tap steps, then two GDN passes of NF steps
+    constexpr int SLOT0 = (3 - (KSTEPS + NF - 1) % 3) % 3;   // ring slot of step 0, such that the first pass ends on slot 0
+    static_assert(NF % 2 == 0, "the GDN mix is split into two halves of the output tiles");
+    static_assert(WPW * NW * 64 == WCH_F4, "a chunk must split evenly into 1 KB pieces per wave");
+    static_assert(NW * TS1_WAVE_BYTES <= (RGB_PATCH + WCH_F4) * 16, "the transposing store must fit in patch + ring slot 0");
     extern __shared__ f4 lds[];
     f4 *patch = lds;
     f4 *wring = lds + RGB_PATCH;                         // 3 x WCH_F4
+    float *beta_lds = (float *)(wring + 3 * WCH_F4);     // COUT floats: read per output tile in the epilogues
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -323,23 +347,36 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
 
     const f4 *wsrc = (const f4 *)p.wpk;
     const f4 *gsrc = (const f4 *)p.gamma_x3;
-    auto dma_chunk = [&](const f4 *chunk_src, int slot) {
+    // Source slot of this lane for each of its pieces.  Weight chunk S: the chunk's own slots, in order.  GDN chunk
+    // (pass, kk): LDS slot l = [k-step 2kk + l / (WCH/2)][section (h, hi|lo) = l % (WCH/2) / HOUT][output l % HOUT of the
+    // pass's half] <- slot [section][HOUT * pass + output] of that k-step's chunk in the gamma image.
+    int goff[WPW];
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int l = (wave * WPW + q) * 64 + lane;
+        const int ks = l / (WCH_F4 / 2), rem = l - ks * (WCH_F4 / 2);
+        const int sec = rem / HOUT, r = rem - sec * HOUT;
+        goff[q] = ks * WCH_F4 + sec * COUT + r;
+    }
+    auto dma_chunk = [&](int c, int slot) {               // chunk of step c (steps past the end: the first again, unused)
+        const bool gdn = c >= KSTEPS && c < NSTEPS;
+        const int g = c - KSTEPS, pass = g >= NF ? 1 : 0, kk = g - pass * NF;
+        const f4 *base = gdn ? gsrc + (int64_t)(2 * kk) * WCH_F4 + pass * HOUT : wsrc + (int64_t)(c < KSTEPS ? c : 0) * WCH_F4;
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
             if (q == 0) dma_mark(wring + slot * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // the last piece's arrival is observed:
             if (q == WPW - 1) dma_marks_stored();                                               // its marks are in LDS before it goes out
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(chunk_src + piece * 64 + lane),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (gdn ? goff[q] : piece * 64 + lane)),
                                              (__attribute__((address_space(3))) void *)(wring + slot * WCH_F4 + piece * 64), 16, 0, 0);
         }
     };
-    // the chunk stream: 8 half chunks of weights, then the 2 NF half chunks of gamma, then (unused) the first again
-    auto stream = [&](int c) -> const f4 * {
-        return c < KSTEPS ? wsrc + (int64_t)c * WCH_F4 : (c < KSTEPS + 2 * NF ? gsrc + (int64_t)(c - KSTEPS) * WCH_F4 : wsrc);
-    };
+    auto next_slot = [](int s) { return s == 2 ? 0 : s + 1; };
+    auto prev_slot = [](int s) { return s == 0 ? 2 : s - 1; };
 
-    dma_chunk(stream(0), 0);
-    dma_chunk(stream(1), 1);
+    dma_chunk(0, SLOT0);
+    dma_chunk(1, next_slot(SLOT0));
+    if (tid < COUT) beta_lds[tid] = p.beta[tid];
     // the image patch: fp32 pixel (4 channels) -> [hi x4 | lo x4] of value * 2^8
     {
         const f4 *img = (const f4 *)p.in + (int64_t)b * p.Hi * p.Wi;
@@ -365,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             if (s < RGB_PR * RGB_ROW) patch[s] = __builtin_bit_cast(f4, two);
         }
     }
-    dma_wait_last(wring + WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // (the second chunk was issued last)
+    dma_wait_last(wring + next_slot(SLOT0) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);   // (the second chunk was issued last)
     __syncthreads();
     MPC_STAMP(1)
     MPC_STAMP_KBEGIN()
@@ -377,10 +414,17 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.0f;
 
     const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * RGB_ROW + (j & 15);
-    int slot = 0;
+    int slot = SLOT0;
+    // end of a step: the chunk issued in it has landed (observed), every wave has read the chunk of the step
+    auto step_end = [&]() {
+        dma_wait_last(wring + prev_slot(slot) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        slot = next_slot(slot);
+    };
 #define MPC_RGB_STEP(S)                                                                                                \
     {                                                                                                                  \
-        dma_chunk(stream((S) + 2), slot >= 1 ? slot - 1 : 2);                                                          \
+        dma_chunk((S) + 2, prev_slot(slot));                                                                           \
         const f4 s0 = bbase[h ? rgb_tap_slot(4 * (S) + 2) : rgb_tap_slot(4 * (S))];                                     \
         const f4 s1 = bbase[h ? rgb_tap_slot(4 * (S) + 3) : rgb_tap_slot(4 * (S) + 1)];                                 \
         const half8 bh = as_half8(f4{s0[0], s0[1], s1[0], s1[1]}), bl = as_half8(f4{s0[2], s0[3], s1[2], s1[3]});       \
@@ -392,10 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        dma_wait_last(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);              \
-        __builtin_amdgcn_s_barrier();                                                                                  \
-        asm volatile("" ::: "memory");                                                                                 \
-        slot = slot == 2 ? 0 : slot + 1;                                                                               \
+        step_end();                                                                                                    \
     }
     MPC_RGB_STEP(0) MPC_RGB_STEP(1) MPC_RGB_STEP(2) MPC_RGB_STEP(3)
     MPC_RGB_STEP(4) MPC_RGB_STEP(5) MPC_RGB_STEP(6) MPC_RGB_STEP(7)
@@ -403,20 +444,24 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
 
     MPC_STAMP(2)
     MPC_STAMP_KEND()
-    // ---- epilogue: scales, bias, the GDN mix as 2 NF more steps, normalisation and full-line stores ----------------
+    // ---- epilogue: scales, bias, the GDN mix in two passes, each followed by its half's normalisation and stores ----
     x3_unscale_bias<NF>(p, acc, 0, h);
     const int64_t opix = ((int64_t)b * p.Ho + oy) * p.Wo + ox;
-    f32x16 nrm[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
-    // the B operand of step (kc, s): the lane's accumulators 8s..8s+7 of tile kc, squared, scaled and split; built one
-    // step ahead, so that the conversions run beside the previous step's MFMAs instead of in front of this step's
-    auto square = [&](int kc, int s2, half8 &bh, half8 &bl) {
+    const bool out_split = (p.flags & MPC_OUT_SPLIT) != 0;
+    // wave-private transposing store, one 32-channel tile of the wave's 32 pixels at a time (see conv_common.h: a lane
+    // owns one pixel and 4 channels per register quad; the rows are flushed with 16-byte stores, 8 lanes per pixel)
+    char *ts_rows = (char *)lds + wave * TS1_WAVE_BYTES;
+    long long *ts_opix = (long long *)(ts_rows + 32 * TS1_ROW_PAD);
+    // the B operand of k-step (kc, s2): the lane's accumulators 8 s2 .. 8 s2 + 7 of tile kc, squared, scaled and split;
+    // built one k-step ahead, so that the conversions run beside the previous k-step's MFMAs instead of in front of
+    // this one's
+    // (second_pass: the value goes through an empty asm statement, so that the compiler does not recognise the squares
+    // of the first pass in it -- it would keep all 12 k-steps' operands, 96 registers, alive across the passes)
+    auto square = [&](int kc, int s2, half8 &bh, half8 &bl, bool second_pass) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             float y = acc[kc][8 * s2 + jj];
+            if (second_pass) asm volatile("" : "+v"(y));
             float q = fminf(y * y * p.y2_scale, 65504.0f);
             _Float16 hh = (_Float16)q;
             bh[jj] = hh;
@@ -424,40 +469,93 @@ __global__ __launch_bounds__(256, 2) void conv1_rgb_patch_x3_kernel(const Params
         }
     };
     half8 bh, bl;
-    square(0, 0, bh, bl);
+    square(0, 0, bh, bl, false);
 #pragma unroll
-    for (int hc = 0; hc < 2 * NF; ++hc) {
-        dma_chunk(stream(KSTEPS + hc + 2), slot >= 1 ? slot - 1 : 2);
-        const f4 *wl = wring + slot * WCH_F4 + (h * 2) * COUT + j;
-        half8 nh = bh, nl = bl;
-        if (hc + 1 < 2 * NF) square((hc + 1) >> 1, (hc + 1) & 1, nh, nl);
+    for (int pass = 0; pass < 2; ++pass) {
+        f32x16 nrm[HF];
 #pragma unroll
-        for (int fo = 0; fo < NF; ++fo) {
-            const half8 ah = as_half8(wl[fo * 32]);
-            const half8 al = as_half8(wl[COUT + fo * 32]);
-            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm[fo], 0, 0, 0);
-            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
-            nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
+        for (int f = 0; f < HF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[f][r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < NF; ++kk) {
+            dma_chunk(KSTEPS + pass * NF + kk + 2, prev_slot(slot));
+            const f4 *wl = wring + slot * WCH_F4 + (h * 2) * HOUT + j;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int hn = 2 * kk + s2 + 1;              // the k-step after this one (the second pass starts over)
+                half8 nh = bh, nl = bl;
+                if (hn < 2 * NF) square(hn >> 1, hn & 1, nh, nl, pass == 1);
+                else if (pass == 0) square(0, 0, nh, nl, true);
+#pragma unroll
+                for (int fo = 0; fo < HF; ++fo) {
+                    const half8 ah = as_half8(wl[s2 * (WCH_F4 / 2) + fo * 32]);
+                    const half8 al = as_half8(wl[s2 * (WCH_F4 / 2) + HOUT + fo * 32]);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, nrm[fo], 0, 0, 0);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, nrm[fo], 0, 0, 0);
+                    nrm[fo] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, nrm[fo], 0, 0, 0);
+                }
+                bh = nh;
+                bl = nl;
+                if (s2 == 0) __builtin_amdgcn_sched_barrier(0);   // (the second k-step's operand reads stay behind the first's MFMAs: registers)
+            }
+            step_end();
         }
-        bh = nh;
-        bl = nl;
-        dma_wait_last(wring + (slot >= 1 ? slot - 1 : 2) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        slot = slot == 2 ? 0 : slot + 1;
+        if (pass == 1) {
+            lds_dma_fence(wring);                        // the surplus pieces have landed before the whole LDS is reused
+            __syncthreads();
+        }
+        MPC_STAMP(3 + pass)
+        // ---- normalise and store this pass's HF tiles: y * (beta + norm)^(-1/2) -------------------------------------
+        if (h == 0) ts_opix[j] = pvalid ? (long long)opix : -1ll;   // (in both passes: ring slot 0 has been written over in between)
+#pragma unroll
+        for (int fl = 0; fl < HF; ++fl) {
+            const int f = pass * HF + fl;
+            __builtin_amdgcn_sched_barrier(0);           // one tile at a time: nothing of the next tile is hoisted (registers)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 be = *(const float4 *)(beta_lds + 32 * f + 8 * g + 4 * h);
+                const float bev[4] = {be.x, be.y, be.z, be.w};
+                float o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float a = nrm[fl][4 * g + t] * p.gdn_unscale + bev[t];
+                    o[t] = acc[f][4 * g + t] * __builtin_amdgcn_rsqf(a);
+                }
+                char *row = ts_rows + j * TS1_ROW_PAD;
+                if (out_split) {
+                    half4 hi4, lo4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float sv = fminf(fmaxf(o[t] * X3_ACT_SCALE, -65504.0f), 65504.0f);
+                        _Float16 hh = (_Float16)sv;
+                        hi4[t] = hh;
+                        lo4[t] = (_Float16)(sv - (float)hh);
+                    }
+                    *(half4 *)(row + g * 32 + 8 * h) = hi4;
+                    *(half4 *)(row + g * 32 + 16 + 8 * h) = lo4;
+                } else {
+                    *(float4 *)(row + (8 * g + 4 * h) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            // flush: 32 pixels x 8 pieces of 16 bytes, consecutive lanes on consecutive bytes of a pixel's 128-byte line
+#pragma unroll
+            for (int i0 = 0; i0 < 32 * 8; i0 += 64) {
+                const int i = i0 + lane, px = i >> 3, pc = i & 7;
+                const long long o = ts_opix[px];
+                if (o >= 0)
+                    *(float4 *)((char *)p.out + o * (long long)(COUT * 4) + f * TS1_ROW_BYTES + pc * 16) = *(const float4 *)(ts_rows + px * TS1_ROW_PAD + pc * 16);
+            }
+        }
+        if (pass == 0) barrier_after_lds_writes();       // every wave has left ring slot 0 before the next step's transfer into it
     }
-    lds_dma_fence(wring + (wave * WPW + WPW - 1) * 64 + lane);                                    // the surplus DMA pieces have landed before the LDS is reused
-    __syncthreads();
-    MPC_STAMP(3)
-    MPC_STAMP(4)
-    x3_gdn_store<NF>(p, acc, nrm, (float4 *)lds, wave, lane, j, h, pvalid ? (long long)opix : -1ll);
     MPC_STAMP(5)
 }
 
 template <int NF>
 int launch_rgb(mpc_ctx *ctx, const Params &p) {
-    size_t lds = ((size_t)RGB_PATCH + 3 * (size_t)NF * 32 * 4) * sizeof(float4);
-    if (lds < (size_t)4 * TS_WAVE_BYTES) lds = (size_t)4 * TS_WAVE_BYTES;
+    size_t lds = ((size_t)RGB_PATCH + 3 * (size_t)NF * 32 * 4) * sizeof(float4) + (size_t)NF * 32 * sizeof(float);
+    lds = patch_kernel_lds(lds);
     auto kern = conv1_rgb_patch_x3_kernel<NF>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
     bool &attr_done = attr_set[ctx->device];

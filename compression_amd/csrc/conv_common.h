@@ -108,6 +108,16 @@ __device__ __forceinline__ int64_t xcd_block() {
 }
 #endif
 
+// Dynamic LDS of the patch kernels.  A measurement build (-DMPC_EXPERIMENT_ONE_WG_PER_CU) asks for more than half of a
+// CU's 160 KB, so that a CU holds one workgroup instead of two: what a layer runs at where another kernel's waves keep
+// its second workgroup out.
+inline size_t patch_kernel_lds(size_t bytes) {
+#ifdef MPC_EXPERIMENT_ONE_WG_PER_CU
+    if (bytes < 81 * 1024) bytes = 81 * 1024;
+#endif
+    return bytes;
+}
+
 // Power-of-two scale of activations stored in the split-fp16 ("S16") format.
 constexpr float X3_ACT_SCALE = 256.0f;
 

@@ -338,6 +338,7 @@ template <int NF, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase) {
     size_t lds = ((size_t)2 * PATCH2_F4 + 4 * (size_t)NF * 32 * 4 + 2 * NF * 8) * sizeof(f4);
     if (EPI == EPI_GDN && lds < (size_t)NW * TS_WAVE_BYTES) lds = (size_t)NW * TS_WAVE_BYTES;
+    lds = patch_kernel_lds(lds);
     auto kern = deconv5s2_patch_f16_kernel<NF, EPI>;
     static bool attr_set[MPC_MAX_DEVICES] = {};
     bool &attr_done = attr_set[ctx->device];

@@ -627,8 +627,13 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
             const int slot = (int)(i & (RING - 1));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[0] + 8 * piece),
                                              (__attribute__((address_space(3))) void *)&ring[slot][0][0], 16, 0, 0);
+#ifndef MPC_EXPERIMENT_HALF_ROWS                           // (measurement build: half of the row traffic, wrong symbols)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[1] + 8 * piece),
                                              (__attribute__((address_space(3))) void *)&ring[slot][2][0], 16, 0, 0);
+#else
+            if (piece < 4) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[1] + 8 * piece),
+                                             (__attribute__((address_space(3))) void *)&ring[slot][2][0], 16, 0, 0);
+#endif
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 if (ci[q] + 1 < ce[q]) {

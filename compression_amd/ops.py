@@ -530,6 +530,12 @@ def rans_decode_from_bytes(table: torch.Tensor, idx: torch.Tensor, streams: List
     return sym
 
 
+def profile_mark(device, mark_id: int) -> None:
+    """One-thread marker kernel on torch's current stream of `device` (shows up in a kernel trace as
+    mpc_profile_mark_kernel)."""
+    context_for(device).call("mpc_profile_mark", int(mark_id))
+
+
 # ---- coder over per-element Laplace rows (never materialised) ---------------------------------------
 def _upload_containers(streams: Sequence[bytes], dev):
     """Byte strings -> (uint8 [B, stride] on the device, their lengths as int64 on the device)."""

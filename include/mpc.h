@@ -52,6 +52,11 @@ const char *mpc_last_error(const mpc_ctx *ctx);
 /* Library build string ("libmpc gfx950 ..."). */
 const char *mpc_version(void);
 
+/* Launches a one-thread kernel named mpc_profile_mark_kernel on the context's stream: a mark in a rocprofv3 kernel
+ * trace (bench.py brackets its timed region with two of them).  No counterpart in the reference, whose timing is
+ * time.perf_counter on the host (src/compression/tests.py:356-372). */
+int mpc_profile_mark(mpc_ctx *ctx, int id);
+
 /* ---- layout helpers ------------------------------------------------------------------------ */
 /* NCHW fp32 [B,C,H,W] -> NHWC [B,H,W,Cpad] (channels C..Cpad-1 zero).  The reference keeps NCHW
  * throughout (e.g. Balle2018PT_compressor.py:98-102); this is the entry conversion. */
