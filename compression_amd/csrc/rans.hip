@@ -475,68 +475,84 @@ __global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g,
 // ---------------------------------------------------------------------------------------------
 // Fast decoder for 256-symbol rows (L = 257, the standard table).
 //
-// The serial chain of a stream is: state -> symbol search in the symbol's CDF row -> new state.  The
-// row of every symbol is known in advance (prior index of the location, channel), so rows are
-// streamed into an LDS ring by LDS-DMA loads (global -> LDS, no registers) DEPTH symbols ahead of
-// their use and retired with counted waits: the coder state only ever waits on LDS.  LDS-DMA writes
-// lane-linear 16-byte pieces, so a wave (four 16-lane groups = four streams) stages the rows of its four
-// streams with two instructions per symbol: piece t of half h of group g's row lands at
-// ring[slot][h][g][t].  The rows come from a copy of the table with a 16-byte aligned row pitch.
-// The symbol is found with a two-level search (16 segment heads, then the 16 entries of the segment),
-// one 16-lane ballot per level.
+// The serial chain of a stream is: state -> symbol search in the symbol's CDF row -> new state.  The row of every
+// symbol is known in advance (prior index of the location, channel), so a loader wave brings rows into an LDS ring a
+// few symbols ahead of their use and the coder state only ever waits on LDS.
+//
+// What is brought is not the 514-byte row but its COMPACT form, 192 bytes, made once per call from the table
+// (compact_rows_kernel): the 16 segment heads row[16 t], each paired with w0 in one 32-bit word (a lane gets both with
+// one read and one register), and the 64 entries of the four consecutive segments that hold the most probability mass
+// (the window, segments w0 .. w0 + 3).  The symbol is found with a two-level
+// search, one 16-lane ballot per level: the segment among the heads, then the entry among the segment's 16.  A state
+// that falls into a segment outside the window (the tails of the distribution: rare) reads that segment from the
+// full table in global memory instead.  Three eighths of the bytes per symbol, and a compact table of 3.1 MB that stays
+// in one XCD's L2 where the 8.6 MB of full rows did not.
+//
+// Rows travel global -> registers -> LDS, one 16-byte load per lane and symbol for the wave's four streams (48 lanes),
+// INFLIGHT symbols deep.  LDS-DMA is not used for them: a CU performs its LDS-DMA transfers in issue order across ALL
+// of its waves, so the first layer of the analysis transform, which runs beside this kernel in the codec pipeline and
+// streams its weights by LDS-DMA, waited behind this kernel's rows at every step (1.28 -> 1.67 ms for that layer).
+// Full rows through registers would have cost the loader 32 registers in flight; with 48 or fewer per wave two waves
+// of this kernel fit a SIMD beside two 208-register waves of that layer.
 // ---------------------------------------------------------------------------------------------
 constexpr int RING = 8;                    // LDS row slots per workgroup (power of two, >= AHEAD + 2)
-constexpr int INFLIGHT = 3;                // rows whose DMA may still be in flight behind the newest issued one
-constexpr int AHEAD = INFLIGHT + 2;        // barriers the loader runs ahead of the decoder: one more than its counted wait
-                                           // needs (vmcnt tells that a row's data has come back, not that the write into
-                                           // LDS has been performed), so every row is read at least one whole step after
-                                           // the wait that retired it
-constexpr int DMA_PITCH = 264;             // row pitch (entries) of the aligned table copy: 528 bytes
-static_assert(NOALLOC_SCRATCH_BYTES == (size_t)NOALLOC_MAX_ROWS * DMA_PITCH * sizeof(uint16_t), "static scratch size");
+constexpr int INFLIGHT = 3;                // rows on their way (in registers) behind the newest loaded one
+constexpr int AHEAD = INFLIGHT + 2;        // barriers the loader runs ahead of the decoder: row n is stored before barrier
+                                           // #(n + INFLIGHT) and read behind barrier #(n + AHEAD)
+constexpr int CROW = 96;                   // 16-bit entries of a compact row: 16 x (head, w0), then the 64 window entries (192 bytes)
+constexpr int CROW_PIECES = CROW / 8;      // 16-byte pieces of a compact row
+constexpr int CROW_WINDOW = 32;            // position of the window
+constexpr int WINDOW_SEGS = 4;
+static_assert(NOALLOC_SCRATCH_BYTES >= (size_t)NOALLOC_MAX_ROWS * CROW * sizeof(uint16_t), "static scratch size");
 constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
 
 // s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
 #define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
-// loader tail: one barrier per remaining row, waiting until at most K rows are in flight before each
-template <int K>
-__device__ __forceinline__ void drain_rows() {
-    MPC_WAIT_VMCNT(2 * (K > 0 ? K : 0));
-    __builtin_amdgcn_s_barrier();
-    if constexpr (K > INFLIGHT - AHEAD) drain_rows<K - 1>();      // K = INFLIGHT - 1 .. INFLIGHT - AHEAD: AHEAD barriers
+// table [rows][257] -> out [rows][CROW]; one 16-lane group per row.
+__global__ __launch_bounds__(256) void compact_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, uint16_t *__restrict__ out) {
+    const int t = threadIdx.x & 15;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (r >= rows) return;                                 // whole groups leave together
+    const uint16_t *row = table + r * 257;
+    uint16_t *o = out + r * CROW;
+    const uint32_t head = row[16 * t];
+    // mass of the window that starts at segment t: row[16 (t + 4)] - row[16 t], the row's end counting as 2^16
+    const uint32_t upper = (t + WINDOW_SEGS <= 15) ? (uint32_t)row[16 * (t + WINDOW_SEGS)] : 0x10000u;
+    uint32_t key = (t <= 16 - WINDOW_SEGS) ? (((upper - head) << 4) | (uint32_t)(15 - t)) : 0u;   // largest mass, then smallest t
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, off, 16));
+    const int w0 = 15 - (int)(key & 15u);
+    ((uint32_t *)o)[t] = head | ((uint32_t)w0 << 16);
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    u16x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = row[16 * w0 + 4 * t + q];
+    *(u16x4 *)(o + CROW_WINDOW + 4 * t) = w;
 }
 
-__global__ void align_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, int L, uint16_t *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * DMA_PITCH) return;
-    int64_t r = i / DMA_PITCH;
-    int c = (int)(i - r * DMA_PITCH);
-    out[i] = c < L ? table[r * L + c] : (uint16_t)0;
-}
-
-// Workgroup = two waves working on the same four streams: wave 1 streams the CDF rows into an LDS ring (the
-// loader), wave 0 runs the coder states, one 16-lane group per stream (the decoder).  Within a wave the
-// hardware keeps DS instructions and LDS-DMA loads in order (a ds_read issued after a DMA waits for it to
-// land), so a wave that both loads and searches serialises on every row; the loader therefore executes no DS
-// instruction in its loop, and the two waves meet at one raw s_barrier per symbol:
-//   loader, iteration i : issue row i (slot i % RING); wait until rows <= i - INFLIGHT have come back; barrier #i
-//   decoder, step n     : barrier #(n + AHEAD); search row n, read the segment heads of row n + 1
-// Barrier #(n + AHEAD) follows the loader's wait for row n + 2: the rows read in step n were retired at least one
-// barrier (one whole step of the coder's chain) earlier.  The loader overwrites the slot of row i - RING only after
-// barrier #(i - 1), which the decoder passes at the top of step i - 1 - AHEAD, when the newest row it can still be
-// reading is row i - 1 - AHEAD > i - RING.  Both waves execute nmax + AHEAD barriers.
+// Workgroup = two waves working on the same four streams: wave 1 brings the compact rows into an LDS ring (the
+// loader), wave 0 runs the coder states, one 16-lane group per stream (the decoder); they meet at one raw s_barrier
+// per symbol:
+//   loader, iteration i : load row i into registers; store row i - INFLIGHT to its ring slot, wait for the store; barrier #i
+//   decoder, step n     : barrier #(n + AHEAD); search row n, read the segment heads and w0 of row n + 1
+// Row n + 1 is in LDS before barrier #(n + 1 + INFLIGHT) <= #(n + AHEAD).  The loader overwrites the slot of row
+// r - RING when it stores row r, behind barrier #(r + INFLIGHT - 1), which the decoder passes no earlier than in
+// step r + INFLIGHT - 1 - AHEAD, when the oldest row it can still read is that step's own: > r - RING.  Both waves
+// execute nmax + AHEAD barriers.
 //
-// The decoder's serial chain per symbol is: ballot over the 16 segment heads (in registers, read a step
-// ahead) -> read the segment's 16 entries -> ballot -> read (start, end) -> new state.  The next
-// renormalisation word is read from an LDS copy of the stream's words a step ahead as well.
-__global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, const uint16_t *__restrict__ table,
-                                                                  const int32_t *__restrict__ idx,
-                                                                  const uint8_t *__restrict__ in, size_t in_stride,
-                                                                  const uint64_t *__restrict__ nbytes,
-                                                                  int16_t *__restrict__ sym_out,
-                                                                  int32_t *__restrict__ status) {
-    static_assert(RING >= AHEAD + 2 && (RING & (RING - 1)) == 0, "ring too small for the DMA lead");
-    __shared__ __attribute__((aligned(16))) uint16_t ring[RING][4][256];         // [slot][group][entry]
+// The decoder's serial chain per symbol is: ballot over the 16 segment heads (in registers, read a step ahead) ->
+// read the segment's 16 entries (window in LDS, or the full table) -> ballot -> (start, end) by lane exchange -> new
+// state.  The next renormalisation word is read from an LDS copy of the stream's words a step ahead as well.
+__global__ __launch_bounds__(128) void decode_streams_ring_kernel(Geometry g, const uint16_t *__restrict__ compact,
+                                                                   const uint16_t *__restrict__ table,
+                                                                   const int32_t *__restrict__ idx,
+                                                                   const uint8_t *__restrict__ in, size_t in_stride,
+                                                                   const uint64_t *__restrict__ nbytes,
+                                                                   int16_t *__restrict__ sym_out,
+                                                                   int32_t *__restrict__ status) {
+    static_assert(RING >= AHEAD + 2 && (RING & (RING - 1)) == 0, "ring too small for the loader's lead");
+    __shared__ __attribute__((aligned(16))) uint16_t ring[RING][4][CROW];        // [slot][group][compact row]
     __shared__ __attribute__((aligned(16))) uint16_t wring[4][WRING];            // renormalisation words per group
     __shared__ uint32_t info[4][3];                                              // per group: first symbol, end symbol, image
     __shared__ uint32_t nmax_sh;
@@ -604,60 +620,60 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
     }
 
     if (loader) {
-        // Each half-wave copies whole rows: lanes 32h..32h+31 bring the 32 16-byte pieces of the row of group h
-        // (first instruction) and of group 2 + h (second instruction); one instruction fills two groups' rows
-        // ([slot][g][256] is lane-linear for it).  Row cursors walk the symbols b, b+1, ... of their stream and
-        // stay on the last symbol at the end (table is the aligned copy: row (k, c) at (k*M + c) * DMA_PITCH).
-        const int hw = lane >> 5, piece = lane & 31;
-        uint32_t ci[2], cc[2], cloc[2], ce[2];
-        const int32_t *cidx[2];
-        const uint16_t *crow[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int gq = 2 * q + hw;
-            const uint32_t qb = info[gq][0];
-            ce[q] = info[gq][1];
-            cidx[q] = idx + (int64_t)info[gq][2] * g.n_loc;
-            ci[q] = qb; cc[q] = qb % M; cloc[q] = qb / M;
-            crow[q] = table;
-            if (qb < ce[q]) crow[q] = table + ((int64_t)cidx[q][cloc[q]] * M + cc[q]) * DMA_PITCH;
+        // Lane l < 48 brings piece l % 12 of the compact row of group l / 12; the ring slot [4][CROW] is lane-linear for
+        // that.  A lane's cursor walks the symbols b, b + 1, ... of its group's stream and stays on the last one at the end.
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const bool active = lane < 4 * CROW_PIECES;
+        const int lg = active ? lane / CROW_PIECES : 0, piece = active ? lane - lg * CROW_PIECES : 0;
+        const uint32_t qb = info[lg][0], ce = info[lg][1];
+        const int32_t *cidx = idx + (int64_t)info[lg][2] * g.n_loc;
+        uint32_t ci = qb, cc = qb % M, cloc = qb / M;
+        const uint16_t *crow = compact + 8 * piece;        // (an empty stream reads row 0: unused)
+        if (qb < ce) crow += ((int64_t)cidx[cloc] * M + cc) * CROW;
+        f4 staged[INFLIGHT + 1];
+        f4 *const dst = (f4 *)&ring[0][0][0] + lane;       // + slot * 4 * CROW_PIECES
+        __builtin_amdgcn_s_waitcnt(0);                     // the set-up's LDS reads are done before the ring is written
+        // iteration i, register u = i % (INFLIGHT + 1): load row i, store row i - INFLIGHT (register (u + 1) % (INFLIGHT + 1)), barrier #i
+#define MPC_LOADER_STEP(U)                                                                                              \
+        {                                                                                                               \
+            if (i < nmax && active) {                                                                                   \
+                staged[U] = *(const f4 *)crow;                                                                          \
+                if (ci + 1 < ce) {                                                                                      \
+                    ++ci;                                                                                               \
+                    if (++cc == M) {                                                                                    \
+                        cc = 0;                                                                                         \
+                        ++cloc;                                                                                         \
+                        crow = compact + 8 * piece + (int64_t)cidx[cloc] * M * CROW;   /* indices were validated above */ \
+                    } else {                                                                                            \
+                        crow += CROW;                                                                                   \
+                    }                                                                                                   \
+                }                                                                                                       \
+            }                                                                                                           \
+            if (i >= (uint32_t)INFLIGHT && i - INFLIGHT < nmax && active)                                               \
+                dst[((i - INFLIGHT) & (RING - 1)) * (4 * CROW_PIECES)] = staged[((U) + 1) % (INFLIGHT + 1)];            \
+            __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));   /* lgkmcnt(0): the row is in LDS */ \
+            __builtin_amdgcn_s_barrier();                  /* #i */                                                     \
+            asm volatile("" ::: "memory");                                                                              \
+            ++i;                                                                                                        \
         }
-        __builtin_amdgcn_s_waitcnt(0);                     // the set-up's LDS reads are done before the first DMA
-        for (uint32_t i = 0; i < nmax; ++i) {
-            const int slot = (int)(i & (RING - 1));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[0] + 8 * piece),
-                                             (__attribute__((address_space(3))) void *)&ring[slot][0][0], 16, 0, 0);
-#ifndef MPC_EXPERIMENT_HALF_ROWS                           // (measurement build: half of the row traffic, wrong symbols)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[1] + 8 * piece),
-                                             (__attribute__((address_space(3))) void *)&ring[slot][2][0], 16, 0, 0);
-#else
-            if (piece < 4) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(crow[1] + 8 * piece),
-                                             (__attribute__((address_space(3))) void *)&ring[slot][2][0], 16, 0, 0);
-#endif
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (ci[q] + 1 < ce[q]) {
-                    ++ci[q];
-                    if (++cc[q] == M) {
-                        cc[q] = 0;
-                        ++cloc[q];
-                        crow[q] = table + (int64_t)cidx[q][cloc[q]] * M * DMA_PITCH;   // indices were validated above
-                    } else {
-                        crow[q] += DMA_PITCH;
-                    }
-                }
-            }
-            MPC_WAIT_VMCNT(2 * INFLIGHT);                  // rows land in order: all but the newest INFLIGHT rows are in LDS
-            __builtin_amdgcn_s_barrier();                  // #i
+        static_assert(INFLIGHT == 3 && AHEAD >= INFLIGHT + 1, "the loader is unrolled over INFLIGHT + 1 = 4 registers");
+        const uint32_t total = nmax + AHEAD;               // barriers #0 .. #(nmax + AHEAD - 1), as many as the decoder wave executes
+        uint32_t i = 0;
+        while (i + 4 <= total) {
+            MPC_LOADER_STEP(0) MPC_LOADER_STEP(1) MPC_LOADER_STEP(2) MPC_LOADER_STEP(3)
         }
-        drain_rows<INFLIGHT - 1>();                        // barriers #nmax .. #(nmax + AHEAD - 1), everything landed by the last
+        if (i < total) MPC_LOADER_STEP(0)
+        if (i < total) MPC_LOADER_STEP(1)
+        if (i < total) MPC_LOADER_STEP(2)
+#undef MPC_LOADER_STEP
         return;
     }
 
     // ---- decoder wave ----
     if (err && live && t == 0) atomicMin(&status[img], err);
     const uint32_t len = e - b;
-    int16_t *dst = sym_out + (int64_t)img * g.n_symbols;
+    // (addresses that are needed once in 16 symbols, or on the rare tail path, are formed from `img` where they are
+    // used: every register counts, 48 is the budget that lets two of these waves sit beside a transform's)
     // the stream's renormalisation words go through an LDS ring of two 128-word halves: lane t brings 8 words
     uint16_t *wr = &wring[gw][0];
     auto fill_half = [&](uint32_t first) {                 // words [first, first + 128) -> ring half (first / 128) & 1
@@ -681,28 +697,39 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
     const uint16_t *rbase = &ring[0][gw][0];               // this group's row in slot 0
 
 #pragma unroll
-    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): rows 0 and 1 have landed
+    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): rows 0 and 1 are in LDS
     asm volatile("" ::: "memory");
-    uint32_t heads = rbase[16 * t];                        // segment heads of row 0
+    uint32_t heads = ((const uint32_t *)rbase)[t];        // segment head t of row 0 (low half) and the row's w0 (high half)
     uint32_t wnext = wr[wpos & (WRING - 1)];
     uint32_t xslot = x & 0xffffu;
     uint32_t mysym = 0;
     for (uint32_t n = 0; n < nmax; ++n) {
-        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows up to n + 2 have landed
+        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows up to n + 1 are in LDS
         asm volatile("" ::: "memory");
-        const uint16_t *row = rbase + (n & (RING - 1)) * (4 * 256);
-        const uint32_t heads_nx = rbase[((n + 1) & (RING - 1)) * (4 * 256) + 16 * t];   // off the chain
+        const uint16_t *row = rbase + (n & (RING - 1)) * (4 * CROW);
+        const uint16_t *row_nx = rbase + ((n + 1) & (RING - 1)) * (4 * CROW);
+        const uint32_t heads_nx = ((const uint32_t *)row_nx)[t];      // off the chain
         if (n < len) {
-            unsigned long long m1 = __ballot(heads <= xslot);
+            unsigned long long m1 = __ballot((heads & 0xffffu) <= xslot);
             uint32_t seg_cnt = __popc((uint32_t)(m1 >> gshift) & 0xffffu);
             uint32_t seg = seg_cnt ? seg_cnt - 1 : 0;      // a row starts at 0, so seg_cnt >= 1 unless the table is corrupt
-            uint32_t ent = row[16 * seg + t];
+            const uint32_t rel = seg - (heads >> 16);
+            const bool inside = rel < (uint32_t)WINDOW_SEGS;
+            uint32_t ent = row[CROW_WINDOW + 16 * (inside ? rel : 0u) + t];
+            if (!inside) {                                  // the state fell into a tail segment: its entries from the full table
+                const uint32_t sidx = b + n;
+                const uint32_t loc = sidx / M, c = sidx - loc * M;
+                const uint16_t *full = table + ((int64_t)idx[(int64_t)img * g.n_loc + loc] * M + c) * 257;
+                ent = full[16 * seg + t];
+            }
             unsigned long long m2 = __ballot(ent <= xslot);
             uint32_t in_seg = __popc((uint32_t)(m2 >> gshift) & 0xffffu);
             uint32_t s = 16 * seg + (in_seg ? in_seg - 1 : 0);
-            uint32_t start = row[s];
-            uint32_t endv = row[s + 1];                    // s = 255 reads the next group's first entry (or the word ring): unused
-            uint32_t end = (s == 255u) ? 0x10000u : endv;
+            // (start, end) = entries s and s + 1: both among the 16 just compared, or the next segment's head, or the row's end
+            const uint32_t start = (uint32_t)__shfl((int)ent, (int)(in_seg ? in_seg - 1 : 0), GROUP);
+            const uint32_t end_in = (uint32_t)__shfl((int)ent, (int)(in_seg & 15u), GROUP);
+            const uint32_t end_hd = (uint32_t)__shfl((int)heads, (int)((seg + 1) & 15u), GROUP) & 0xffffu;
+            const uint32_t end = in_seg < 16u ? end_in : (seg == 15u ? 0x10000u : end_hd);
             x = (end - start) * (x >> 16) + xslot - start;
             const bool ren = x < RANS_L;
             if (ren) x = (x << 16) | wnext;
@@ -722,7 +749,7 @@ __global__ __launch_bounds__(128) void decode_streams_dma_kernel(Geometry g, con
             if (t == (int)(n & 15)) mysym = s;
             if ((n & 15) == 15 || n + 1 == len) {
                 uint32_t first = n & ~15u;
-                if (first + t <= n) dst[b + first + t] = decoded_value(g, (int)mysym);
+                if (first + t <= n) sym_out[(int64_t)img * g.n_symbols + b + first + t] = decoded_value(g, (int)mysym);
             }
         }
         heads = heads_nx;
@@ -872,21 +899,21 @@ int mpc_rans_encode_auto(mpc_ctx *ctx, const int16_t *table, int K, int M, int L
 
 }  // extern "C"
 
-// Shared body of the two decode entry points.  `aligned_rows`: device buffer of K*M*DMA_PITCH uint16 for the
-// 16-byte aligned copy of the table (L == 257 only; unused otherwise).
+// Shared body of the two decode entry points.  `compact_rows`: device buffer of K*M*CROW uint16 for the compact form
+// of the table (L == 257 only; unused otherwise).
 static int rans_decode_launch(mpc_ctx *ctx, const Geometry &g, const int16_t *table, const int32_t *idx, const uint8_t *in,
                               size_t in_stride, const uint64_t *nbytes_dev, int16_t *sym_out, int32_t *status_dev,
-                              void *aligned_rows) {
+                              void *compact_rows) {
     const int64_t G = (int64_t)g.n_images * g.n_streams;
     MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
     if (g.L == 257) {
-        // aligned copy of the table for the LDS-DMA row loads (rebuilt per call: the caller may have changed the table)
+        // compact form of the table for the loader wave (rebuilt per call: the caller may have changed the table)
         const int64_t rows = (int64_t)g.K * g.M;
-        align_rows_kernel<<<dim3((unsigned)mpc_cdiv(rows * DMA_PITCH, 256)), dim3(256), 0, ctx->stream>>>(
-            (const uint16_t *)table, rows, g.L, (uint16_t *)aligned_rows);
-        MPC_CHECK_LAUNCH(ctx, "rans align_rows");
-        decode_streams_dma_kernel<<<dim3((unsigned)mpc_cdiv(G, 4)), dim3(128), 0, ctx->stream>>>(
-            g, (const uint16_t *)aligned_rows, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+        compact_rows_kernel<<<dim3((unsigned)mpc_cdiv(rows, 16)), dim3(256), 0, ctx->stream>>>((const uint16_t *)table, rows,
+                                                                                            (uint16_t *)compact_rows);
+        MPC_CHECK_LAUNCH(ctx, "rans compact_rows");
+        decode_streams_ring_kernel<<<dim3((unsigned)mpc_cdiv(G, 4)), dim3(128), 0, ctx->stream>>>(
+            g, (const uint16_t *)compact_rows, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
     } else {
         decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
             g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
@@ -922,7 +949,7 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     if (rc) return rc;
     void *aligned = nullptr;
     if (L == 257) {
-        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * DMA_PITCH * sizeof(uint16_t));
+        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
         if (!aligned) return MPC_EHIP;
     }
     rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
@@ -946,7 +973,7 @@ int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M,
     g.lat_q = q_intv;
     void *aligned = nullptr;
     if (L == 257) {
-        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * DMA_PITCH * sizeof(uint16_t));
+        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
         if (!aligned) return MPC_EHIP;
     }
     rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, (int16_t *)latent_f16_out, status_dev, aligned);
@@ -970,10 +997,10 @@ int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, in
     MPC_REQUIRE(ctx, L == 257, "rans_decode_noalloc: only tables with 257 entries per row (256 symbols) are supported");
     MPC_REQUIRE(ctx, (int64_t)K * M <= NOALLOC_MAX_ROWS,
                 "rans_decode_noalloc: K*M = %lld table rows exceed the static scratch (%d rows of %d bytes); use mpc_rans_decode",
-                (long long)K * M, NOALLOC_MAX_ROWS, DMA_PITCH * 2);
+                (long long)K * M, NOALLOC_MAX_ROWS, CROW * 2);
     void *aligned = ctx->device >= 0 && ctx->device < MPC_MAX_DEVICES ? static_scratch_ptr[ctx->device] : nullptr;
     MPC_REQUIRE(ctx, aligned != nullptr, "rans_decode_noalloc: the static scratch of device %d was not initialised", ctx->device);
-    // align_rows_kernel rewrites every byte of the K*M rows this call reads, so the previous call's contents never show
+    // compact_rows_kernel rewrites every byte of the K*M rows this call reads, so the previous call's contents never show
     return rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
 }
 
