@@ -308,3 +308,34 @@ def test_laplace_coder_equals_the_coder_over_materialised_rows(dev, ops, Lrow, M
     assert st_enc.cpu()[0].item() == -10
     with pytest.raises(Exception, match="257"):
         ops.rans_encode_laplace(sig_d, sym_d, n_img, Mch, first, 300, 16, n_streams, lps)
+
+
+def test_fast_decoder_outside_its_row_window(dev, ops):
+    """The 256-symbol decoder works on compact rows: the 16 segment heads and the 64 entries of the four heaviest
+    consecutive segments; a state that falls into any other segment takes the segment from the full table.  Here most
+    symbols do: wide rows (Laplace scales 20 .. 200, and exactly uniform rows) coded with symbols drawn uniformly from
+    all 256 values, the window at either end of the row for some rows.  The GPU bytes equal the scalar specification's,
+    the independent C decoder and the GPU decoder both return the symbols."""
+    K2, M2, n_img, n_loc, n_streams = 4, 32, 2, 50, 7
+    g = torch.Generator().manual_seed(77)
+    t = torch.linspace(-127.5, 128.5, 257)
+    scale = torch.exp(torch.rand(K2, M2, 1, generator=g) * 2.3 + 3.0)
+    centre = (torch.rand(K2, M2, 1, generator=g) - 0.5) * 300.0          # modes beyond both ends of the row as well
+    tf = 0.5 - 0.5 * torch.sign(t - centre) * torch.expm1(-(t - centre).abs() / scale)
+    tf[0, :4] = torch.linspace(0.0, 1.0, 257)                            # uniform rows: every window holds the same mass
+    table = O.renorm_cast_cdf(tf.contiguous(), 16, 0)
+    idx = torch.randint(0, K2, (n_img, n_loc), generator=g, dtype=torch.int32)
+    sym = torch.randint(0, 256, (n_img, n_loc * M2), generator=g, dtype=torch.int16)
+    lps = -(-n_loc // n_streams)
+    td, idxd = table.to(dev), idx.reshape(-1).to(dev)
+    out, nbytes, status = ops.rans_encode(td, idxd, sym.reshape(-1).to(dev), n_img, n_streams, lps)
+    assert status.cpu().tolist() == [0] * n_img
+    nb = nbytes.cpu().tolist()
+    tnp = table.numpy()
+    for i in range(n_img):
+        got = out[i, :nb[i]].cpu().numpy().tobytes()
+        assert got == coders.mrs1_encode(tnp, idx[i].numpy(), sym[i].numpy(), n_streams, lps * M2)
+        assert np.array_equal(coders.mrs1_decode(tnp, idx[i].numpy(), got), sym[i].numpy())
+    dec, st = ops.rans_decode(td, idxd, out, nbytes, n_img, n_streams, lps)
+    assert st.cpu().tolist() == [0] * n_img
+    assert torch.equal(dec.cpu(), sym)

@@ -7,7 +7,7 @@ O=gpurun_out/$N; mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python3 bench.py --steps 50 --warmup 2 --no-cpu-baseline > $O/trace.log 2>&1 || { echo "trace failed"; tail -5 $O/trace.log; exit 1; }
 ls $O/trace
-python3 tools/region_stats.py $O/trace/trace_kernel_trace.csv > $O/kernel_stats_timed.csv || { echo "region stats failed"; exit 1; }
+python3 tools/region_stats.py $O/trace/trace_kernel_trace.csv 50 > $O/kernel_stats_timed.csv || { echo "region stats failed"; exit 1; }
 head -12 $O/kernel_stats_timed.csv
 grep '^{' $O/trace.log | tail -1 > $O/bench_under_trace.json
 rm -f $O/trace/trace_kernel_trace.csv          # tens of MB; its digest is kept

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel statistics of the TIMED REGION of a profiled bench.py run.
 
-usage: python tools/region_stats.py <rocprofv3 ..._kernel_trace.csv> [> profiles/rN_kernel_stats_timed.csv]
+usage: python tools/region_stats.py <rocprofv3 ..._kernel_trace.csv> [timed steps] [> profiles/rN_kernel_stats_timed.csv]
 
 bench.py launches a one-thread kernel (mpc_profile_mark_kernel) right before its timed region starts and right after it
 ends.  This script keeps the launches that start between the first two such marks of the trace -- so the warm-up steps
@@ -16,7 +16,7 @@ from collections import defaultdict
 MARK = "mpc_profile_mark_kernel"
 
 
-def main(path):
+def main(path, steps=0):
     rows = list(csv.DictReader(open(path, newline="")))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     marks = [r for r in rows if MARK in r["Kernel_Name"]]
@@ -35,7 +35,14 @@ def main(path):
         v = per[k]
         w.writerow([k, len(v), sum(v), f"{sum(v) / len(v):.1f}", min(v), max(v), f"{100.0 * sum(v) / total:.2f}"])
     w.writerow(["(wall time between the two marks)", 1, t_end - t_begin, t_end - t_begin, t_end - t_begin, t_end - t_begin, ""])
+    # a kernel launched several times per step (the same layer kernel for different layers): the average per position in the step
+    if steps:
+        for k in sorted(per, key=lambda k: -sum(per[k])):
+            v = per[k]
+            m = len(v) // steps
+            if m > 1 and len(v) == m * steps:
+                w.writerow([k + " -- average by position in the step"] + [f"{sum(v[i::m]) / steps:.1f}" for i in range(m)])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
