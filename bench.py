@@ -619,15 +619,16 @@ def run_rank(args):
     # the materialised per-symbol CDF rows ("CDF build") at the workload's size: measured on its own, the fused coder
     # never needs this tensor
     n_loc_probe = min(36864, B * (H // 16) * (W // 16))
-    idx_probe = torch.randint(0, 64, (n_loc_probe,), dtype=torch.int32, device=dev)
-    model._ensure_tables()
-    rows = ops.gather_cdf(model.entropy_table, idx_probe)
-    p2 = ops.PROFILER = ops.Profiler()
-    for _ in range(5):
-        ops.gather_cdf(model.entropy_table, idx_probe, out=rows)
-    ops.PROFILER = None
-    kern.update(p2.summary())
-    del rows
+    if args.mode != "hp_codec":                              # (the hyperprior models have no table of priors to gather from)
+        idx_probe = torch.randint(0, 64, (n_loc_probe,), dtype=torch.int32, device=dev)
+        model._ensure_tables()
+        rows = ops.gather_cdf(model.entropy_table, idx_probe)
+        p2 = ops.PROFILER = ops.Profiler()
+        for _ in range(5):
+            ops.gather_cdf(model.entropy_table, idx_probe, out=rows)
+        ops.PROFILER = None
+        kern.update(p2.summary())
+        del rows
 
     if rank != 0:
         if dist is not None:

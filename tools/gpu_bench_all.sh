@@ -7,4 +7,5 @@ import json; d=json.load(open("$O/$name.json")); print("$name", round(d["value"]
 PY
 }
 run config3 && run config3_serial --serial --no-cpu-baseline && run config3_smooth --data smooth --no-cpu-baseline && run config1 --config 1 --no-cpu-baseline --steps 50 && run config2 --config 2 --no-cpu-baseline --steps 50 \
- && run config4 --config 4 --no-cpu-baseline && run config5 --config 5 --no-cpu-baseline && run config5_testolina --config 5 --arch TestolinaManyPriors --no-cpu-baseline
+ && run config4 --config 4 --no-cpu-baseline && run config5 --config 5 --no-cpu-baseline && run config5_testolina --config 5 --arch TestolinaManyPriors --no-cpu-baseline \
+ && run config6_hyperprior --config 6 --steps 10 && run config6_balle2018 --config 6 --arch Balle2018PTTFExp --steps 10
