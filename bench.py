@@ -82,7 +82,7 @@ def kernel_peak(name):
     """(peak TFLOP/s of the MFMA type the kernel issues, MFMA instructions issued per algorithmic product)."""
     if name.startswith("conv_igemm_x3") or name.startswith("conv5s2_patch_x3") or name.startswith("conv1_rgb_patch_x3"):
         return PEAK_F16_MFMA_TFLOPS, 3        # a = hi + lo: three fp16 MFMAs per product
-    if name.startswith("conv_igemm_f16") or name.startswith("deconv5s2_patch_f16"):
+    if name.startswith("conv_igemm_f16") or name.startswith("deconv5s2_patch_f16") or name.startswith("deconv_rgb16"):
         return PEAK_F16_MFMA_TFLOPS, 1
     return PEAK_F32_MFMA_TFLOPS, 1
 
@@ -151,6 +151,7 @@ def parse(argv=None):
     ap.add_argument("--synthesis-precision", default="fp16", choices=["fp32", "fp16"])
     ap.add_argument("--serial", action="store_true",
                     help="codec workloads: one batch after the other on one stream (default: two batches in flight on two streams)")
+    ap.add_argument("--forward-depth", type=int, default=3, help="forward workloads: batches in flight (ForwardPipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=40, help="images of the CPU baseline's sample at the larger thread count")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
@@ -487,7 +488,7 @@ def run_rank(args):
     fpipe = None
     if args.mode == "forward" and not args.serial:
         from compression_amd.pipeline import ForwardPipeline
-        fpipe = ForwardPipeline(model, dev, depth=2)
+        fpipe = ForwardPipeline(model, dev, depth=args.forward_depth)
 
     def forward_stats(out, stream):
         """Statistics of one finished forward, formed on the stream that holds its tensors."""
@@ -660,7 +661,7 @@ def run_rank(args):
                                f"random-init weights with spread priors, {args.data} input",
                    "images_per_gpu": B, "height": H, "width": W, "bpp": stats["bpp"],
                    "parallelism": f"image-sharded x{world}, statistics all-reduce only",
-                   "batches_in_flight": 2 if (pipe is not None or fpipe is not None) else 1, "warmup_steps_run": n_warm,
+                   "batches_in_flight": (args.forward_depth if fpipe is not None else 2) if (pipe is not None or fpipe is not None) else 1, "warmup_steps_run": n_warm,
                    "post_pass_steps": post_steps},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_profiled_at": profiled_at,

@@ -119,8 +119,11 @@ class ForwardPipeline:
         self.model = model
         self.device = torch.device(device)
         self.depth = depth
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(min(depth, 2))]
-        self.pool = ThreadPoolExecutor(max_workers=1)
+        # one stream per batch in flight (the page-locked readback buffers are per stream: a batch's host part may still
+        # be reading its buffer when the batch after next is enqueued) and one worker less than that: with two batches in
+        # flight one worker keeps up; the LZMA call, numpy and the event wait all release the interpreter lock
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(depth)]
+        self.pool = ThreadPoolExecutor(max_workers=max(1, depth - 1))
         self.queue = []              # (input, job, future of its host part, tag, stream), oldest first
         self.count = 0
         for s in self.streams:
