@@ -522,7 +522,7 @@ def test_scored_synthesis_matches_clamp_and_sse_pass(model_fp16, dev, hw):
 
 
 def test_forward_pipeline_matches_one_forward_at_a_time(model_fp16, dev):
-    """ForwardPipeline (two batches in flight, the host's share on a worker thread) returns, for every batch, the
+    """ForwardPipeline (two or three batches in flight, the host's share on worker threads) returns, for every batch, the
     dictionary that model(x) returns: same reconstruction bits, same rate and side-string cost to the bit, same priors
     used, in submission order -- including a batch whose latents leave the tables' range (the tables are widened and
     the batches in flight run again, as model(x) would)."""
@@ -531,21 +531,22 @@ def test_forward_pipeline_matches_one_forward_at_a_time(model_fp16, dev):
     xs = [synth.rand_image(300 + i, 2, 64, 96).to(dev) for i in range(5)]
     want = [m(x) for x in xs]
     torch.cuda.synchronize()
-    pipe = ForwardPipeline(m, dev, depth=2)
-    got = []
-    for i, x in enumerate(xs):
-        r = pipe.submit(x, tag=i)
-        if r is not None:
-            got.append(r)
-    got += pipe.flush()
-    pipe.synchronize()
-    assert [t for _, t in got] == list(range(5))
-    for (out, _), ref in zip(got, want):
-        assert torch.equal(out["reconstructed_image"], ref["reconstructed_image"])
-        for key in ("bpp_feature", "bpp_sidestring", "bpp", "visual_loss"):
-            assert float(out[key]) == float(ref[key]), key
-        assert out["used_dists"] == ref["used_dists"]
-    pipe.close()
+    for depth in (2, 3):                                     # (3: what bench.py uses; one stream and readback buffer per batch in flight)
+        pipe = ForwardPipeline(m, dev, depth=depth)
+        got = []
+        for i, x in enumerate(xs):
+            r = pipe.submit(x, tag=i)
+            if r is not None:
+                got.append(r)
+        got += pipe.flush()
+        pipe.synchronize()
+        assert [t for _, t in got] == list(range(5))
+        for (out, _), ref in zip(got, want):
+            assert torch.equal(out["reconstructed_image"], ref["reconstructed_image"])
+            for key in ("bpp_feature", "bpp_sidestring", "bpp", "visual_loss"):
+                assert float(out[key]) == float(ref[key]), key
+            assert out["used_dists"] == ref["used_dists"]
+        pipe.close()
     # latents outside the tables' range: two models with a narrow range, one called batch by batch, one through the pipeline
     import compression_amd as ca
     sd8 = synth.manypriors_state_dict(234, N, M, 8, spread=True)
@@ -557,7 +558,7 @@ def test_forward_pipeline_matches_one_forward_at_a_time(model_fp16, dev):
     ys = [synth.rand_image(310 + i, 1, 64, 64).to(dev) for i in range(3)]
     want = [models[0](y) for y in ys]
     assert models[0].max_feat > 4, "these inputs were meant to leave the tables' range"
-    pipe = ForwardPipeline(models[1], dev, depth=2)
+    pipe = ForwardPipeline(models[1], dev, depth=3)
     got = []
     for i, y in enumerate(ys):
         r = pipe.submit(y, tag=i)
