@@ -481,6 +481,9 @@ def run_rank(args):
         state["acc"] = a
         return xhat
 
+    if os.environ.get("MPC_BENCH_SYNTHESIS_BEHIND_LAYER"):    # (A/B switch, see manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER)
+        from compression_amd import manynets_compressor
+        manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER = int(os.environ["MPC_BENCH_SYNTHESIS_BEHIND_LAYER"])
     pipe = None
     if args.mode == "codec" and not args.serial:
         from compression_amd.pipeline import CodecPipeline

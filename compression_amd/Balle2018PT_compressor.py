@@ -96,13 +96,17 @@ class Analysis_net(_FusedNet):
 
     def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False, events=None):
         """x4 -> (round(y) | None, int16 symbols NHWC, clamped count): quantisation and symbolisation run in the last
-        layer's epilogue.  events (a dict): receives "layer3_done", an event recorded behind the third layer."""
+        layer's epilogue.  events (a dict): receives "layer2_done" and "layer3_done", events recorded behind the second and the third layer."""
         l1, l2, l3, l4 = self.layers()
-        if self.precision == "f16x3":
+        split = self.precision == "f16x3"
+        if split:
             self._check_split_range()
-            t = l3(l2(l1(x4, out_split=True), out_split=True), out_split=True)
-        else:
-            t = l3(l2(l1(x4)))
+        kw = dict(out_split=True) if split else {}
+        t = l2(l1(x4, **kw), **kw)
+        if events is not None:
+            events["layer2_done"] = torch.cuda.Event()
+            events["layer2_done"].record()
+        t = l3(t, **kw)
         if events is not None:
             events["layer3_done"] = torch.cuda.Event()
             events["layer3_done"].record()

@@ -20,9 +20,11 @@ from .Balle2018PT_compressor import Analysis_net, Synthesis_net
 from .bitEstimator import MultiHeadBitEstimator
 
 TRY_PNG_SIDESTRING = True      # pt_helpers.get_num_bits(try_png=...) for bpp_sidestring
-# Stress knob for tests of the LDS-DMA hazard: a pipelined caller then starts g_s(n-1) behind the THIRD layer of g_a(n),
-# so that the first transposed layers run beside the last analysis layer (wrong tiles, a few per thousand steps).
-STRESS_OVERLAP_TRANSFORMS = False
+# The event of encode_batch_begin that a pipelined caller lets the previous batch's g_s wait for ("transforms_done") is
+# recorded behind this layer of g_a: 4 = behind all of it (the two transforms never share the CUs), 3 = behind the third
+# layer, so that the first transposed layers run beside the last analysis layer (+1.5 % in the codec pipeline: that
+# layer alone does not fill the chip), 2 = behind the second (no faster; what the side-by-side test uses).
+SYNTHESIS_MAY_START_BEHIND_LAYER = 3
 HOST_TRACE = None              # a list: encode_batch / decode_batch append (label, time.perf_counter()) at their host-side milestones
 
 
@@ -373,8 +375,8 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         _, sym4, _ = self.Encoder.forward_symbols(x4, self.min_feat, self._n_targets() - 1, nclamp_d, events=events)
         transforms_done = torch.cuda.Event()
         transforms_done.record()
-        if STRESS_OVERLAP_TRANSFORMS:
-            transforms_done = events["layer3_done"]
+        if SYNTHESIS_MAY_START_BEHIND_LAYER in (2, 3):
+            transforms_done = events["layer%d_done" % SYNTHESIS_MAY_START_BEHIND_LAYER]
         _, h, w, _ = sym4.shape
         sym = sym4.view(-1, M)
         idx, minbits, _ = ops.prior_argmin(sym, self._lut_ln)

@@ -8,13 +8,12 @@ batches are independent, so this driver keeps two in flight, each on its own str
     stream of batch n     : g_a(n) | competition, encoder(n) | host: bytes of n | ........ wait ....... | decoder(n) | g_s(n)
     stream of batch n - 1 : decoder(n-1) | wait | g_s(n-1) .....................| g_a(n+1) ............................
 
-the two transforms never run beside each other (g_s(n-1) waits for an event behind g_a(n); g_a(n+1) is enqueued behind
-g_s(n-1) on the same stream: two MFMA-bound kernels that share the CUs only slow each other, measured 12 % worse than
-no pipelining at all; and this order is also a matter of correctness -- with the first layers of g_s(n-1) beside the last
-layer of g_a(n), a few steps per thousand had a wrong tile in that layer: an LDS-DMA kernel must not share a CU with
-another transform kernel, see lds DMA notes in csrc/conv_common.h), the encoder runs beside g_s(n-1), and the decoder of a batch, held back until the g_s before it
-has ended, beside the first layer of the next g_a (beside the second layer instead it costs the dominant kernel 9 % of
-its rate for 0.6 % of throughput).  Every batch still goes
+the bulk of the two transforms never runs side by side (g_s(n-1) waits for an event behind the third layer of g_a(n),
+manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER, so only the last analysis layer -- too small to fill the chip --
+shares the CUs with the first transposed layers: +1.5 %; g_a(n+1) is enqueued behind g_s(n-1) on the same stream.  Two
+MFMA-bound kernels that share the CUs for long only slow each other: measured 12 % worse than no pipelining at all),
+the encoder runs beside g_s(n-1), and the decoder of a batch, held back until the g_s before it has ended, beside the
+first layer of the next g_a (both kernels are built to fit a SIMD together: 2 x 208 + 2 x 48 registers).  Every batch still goes
 encode -> bytes on the host -> decode; only the order in which the host enqueues the phases changes
 (encode_batch_begin/finish, decode_batch_begin/synthesis/finish of the model).  The reference codes one image at a
 time on one stream (src/compression/tests.py:439-460); it has no counterpart of this driver.

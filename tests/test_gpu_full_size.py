@@ -103,13 +103,12 @@ def test_two_batches_in_flight_repeat_the_same_bits(dev):
 
 
 def test_transforms_side_by_side_give_the_same_bits(dev):
-    """g_s of one batch started behind the THIRD layer of the next batch's g_a, so that the transposed layers share the
-    CUs with the last analysis layer (CodecPipeline never does that: it is slower), 600 steps: every result equals the
-    one-batch-at-a-time result.  Regression test of the patch kernels' barriers: when a wave could arrive at the tap's
-    s_barrier with its ds_write of the next weight chunk still queued (no lgkmcnt(0) in front of the barrier), the
-    waves that left the barrier first read the old chunk, and 3 of 1 000 such steps had a few wrong symbols in one
-    wave's 32 pixels of the last analysis layer -- only in this placement, where the other kernel keeps the CU's LDS
-    busy."""
+    """g_s of one batch started behind the SECOND layer of the next batch's g_a, so that the transposed layers share the
+    CUs with the third and the last analysis layer (CodecPipeline starts it behind the third by default), 600 steps:
+    every result equals the one-batch-at-a-time result.  Regression test of the patch kernels' barriers: when a wave
+    could arrive at the tap's s_barrier with its ds_write of the next weight chunk still queued (no lgkmcnt(0) in front of
+    the barrier), the waves that left the barrier first read the old chunk, and 3 of 1 000 steps had a few wrong symbols
+    in one wave's 32 pixels of the last analysis layer -- only when another transform kernel kept the CU's LDS busy."""
     from compression_amd import manynets_compressor
     from compression_amd.pipeline import CodecPipeline
     m = _model(dev, analysis_precision="f16x3", synthesis_precision="fp16")
@@ -118,7 +117,8 @@ def test_transforms_side_by_side_give_the_same_bits(dev):
     recon = m.decode_batch(strings, idx, h, w).clone()
     torch.cuda.synchronize()
     bad = []
-    manynets_compressor.STRESS_OVERLAP_TRANSFORMS = True
+    default = manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER
+    manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER = 2
     try:
         pipe = CodecPipeline(m, dev)
 
@@ -133,5 +133,5 @@ def test_transforms_side_by_side_give_the_same_bits(dev):
                 check(r)
         check(pipe.flush())
     finally:
-        manynets_compressor.STRESS_OVERLAP_TRANSFORMS = False
+        manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER = default
     assert not bad, f"steps {bad} differ from the one-batch-at-a-time result"
