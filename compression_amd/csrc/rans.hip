@@ -18,11 +18,12 @@
 // possible.
 #include "mpc_internal.h"
 
-// Scratch of the allocation-free decode entry point: the 16-byte aligned copy of the CDF table, at most
-// NOALLOC_MAX_ROWS rows (the standard model has K*M = 64*256 of them) of 528 bytes = 8.25 MiB per GPU, held until the
-// process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; kernels get the per-device address.
+// Scratch of the allocation-free decode entry point: the compact copy of the CDF table (192 bytes per row, see the fast
+// decoder below), at most NOALLOC_MAX_ROWS rows (the standard model has K*M = 64*256 of them) = 3 MiB per GPU, held until
+// the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; kernels get the per-device address.
 constexpr int NOALLOC_MAX_ROWS = 64 * 256;
-constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_MAX_ROWS * 264 * sizeof(uint16_t);
+constexpr int CROW = 96;                   // 16-bit entries of a compact row: 16 x (head, w0), then the 64 window entries (192 bytes)
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_MAX_ROWS * CROW * sizeof(uint16_t);
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 static void *static_scratch_ptr[MPC_MAX_DEVICES] = {};
 
@@ -499,11 +500,9 @@ constexpr int RING = 8;                    // LDS row slots per workgroup (power
 constexpr int INFLIGHT = 3;                // rows on their way (in registers) behind the newest loaded one
 constexpr int AHEAD = INFLIGHT + 2;        // barriers the loader runs ahead of the decoder: row n is stored before barrier
                                            // #(n + INFLIGHT) and read behind barrier #(n + AHEAD)
-constexpr int CROW = 96;                   // 16-bit entries of a compact row: 16 x (head, w0), then the 64 window entries (192 bytes)
-constexpr int CROW_PIECES = CROW / 8;      // 16-byte pieces of a compact row
+constexpr int CROW_PIECES = CROW / 8;      // 16-byte pieces of a compact row (CROW entries: 16 x (head, w0), then the 64 window entries)
 constexpr int CROW_WINDOW = 32;            // position of the window
 constexpr int WINDOW_SEGS = 4;
-static_assert(NOALLOC_SCRATCH_BYTES >= (size_t)NOALLOC_MAX_ROWS * CROW * sizeof(uint16_t), "static scratch size");
 constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
 
 // s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
@@ -947,12 +946,12 @@ int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, con
     int rc = rans_decode_check(ctx, g, table, K, M, L, idx, in, in_stride, nbytes_dev, n_images, n_loc, n_streams,
                                locs_per_stream, sym_out, status_dev);
     if (rc) return rc;
-    void *aligned = nullptr;
+    void *compact = nullptr;
     if (L == 257) {
-        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
-        if (!aligned) return MPC_EHIP;
+        compact = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
+        if (!compact) return MPC_EHIP;
     }
-    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, compact);
     if (L == 257) mpc_ctx_scratch_release(ctx);
     return rc;
 }
@@ -971,18 +970,18 @@ int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M,
     g.latent_f16 = 1;
     g.lat_min = min_feat;
     g.lat_q = q_intv;
-    void *aligned = nullptr;
+    void *compact = nullptr;
     if (L == 257) {
-        aligned = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
-        if (!aligned) return MPC_EHIP;
+        compact = mpc_ctx_scratch(ctx, (size_t)K * M * CROW * sizeof(uint16_t));
+        if (!compact) return MPC_EHIP;
     }
-    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, (int16_t *)latent_f16_out, status_dev, aligned);
+    rc = rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, (int16_t *)latent_f16_out, status_dev, compact);
     if (L == 257) mpc_ctx_scratch_release(ctx);
     return rc;
 }
 
 // ---- decode without any allocation ------------------------------------------------------------------------------
-// mpc_rans_decode keeps its aligned copy of the table in context scratch that it allocates on demand.  Callers that
+// mpc_rans_decode keeps its compact copy of the table in context scratch that it allocates on demand.  Callers that
 // may not allocate (code under HIP graph capture, tight serving loops) use mpc_rans_decode_noalloc instead: the same
 // kernels, with the copy in the file-scope device array below.  Every GPU holds its own instance of the array at its
 // own address, found once per device by mpc_rans_static_init (called from mpc_create with that device current).
@@ -998,10 +997,10 @@ int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, in
     MPC_REQUIRE(ctx, (int64_t)K * M <= NOALLOC_MAX_ROWS,
                 "rans_decode_noalloc: K*M = %lld table rows exceed the static scratch (%d rows of %d bytes); use mpc_rans_decode",
                 (long long)K * M, NOALLOC_MAX_ROWS, CROW * 2);
-    void *aligned = ctx->device >= 0 && ctx->device < MPC_MAX_DEVICES ? static_scratch_ptr[ctx->device] : nullptr;
-    MPC_REQUIRE(ctx, aligned != nullptr, "rans_decode_noalloc: the static scratch of device %d was not initialised", ctx->device);
+    void *compact = ctx->device >= 0 && ctx->device < MPC_MAX_DEVICES ? static_scratch_ptr[ctx->device] : nullptr;
+    MPC_REQUIRE(ctx, compact != nullptr, "rans_decode_noalloc: the static scratch of device %d was not initialised", ctx->device);
     // compact_rows_kernel rewrites every byte of the K*M rows this call reads, so the previous call's contents never show
-    return rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, aligned);
+    return rans_decode_launch(ctx, g, table, idx, in, in_stride, nbytes_dev, sym_out, status_dev, compact);
 }
 
 }  // extern "C"

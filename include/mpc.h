@@ -12,8 +12,8 @@
  *     parameter is documented as host memory; the caller owns every buffer it passes;
  *   - work is enqueued on the context's HIP stream and is asynchronous unless stated otherwise;
  *   - a context is not thread-safe; distinct contexts may be used from distinct threads;
- *   - a context owns one device scratch buffer that grows on demand (the decoder's copy of the CDF table
- *     with aligned rows); calls on one context must therefore not overlap in time on different streams.
+ *   - a context owns one device scratch buffer that grows on demand (the decoder's compact copy of the CDF
+ *     table); calls on one context must therefore not overlap in time on different streams.
  *
  * Activations are NHWC ([B][H][W][C], C contiguous): fp32 on the exact path, fp16 between MPC_F16 layers, the
  * split format described at MPC_F16X3 between split-precision layers.  The quantised latent in NHWC IS the
@@ -195,8 +195,9 @@ int mpc_rans_encode_auto(mpc_ctx *ctx, const int16_t *table, int K, int M, int L
  * into sym_out + i*n_loc*M.  n_streams / locs_per_stream are the values the containers were written
  * with (fields 1 and 3 of the header; every image of the batch must share them).  status_dev[i]
  * (device int32) is 0 or a negative detail code of MPC_EDATA.  Tables with L = 257 (256-symbol rows, the standard
- * model) take the fast path: rows streamed into LDS by a loader wave, searched by a decoder wave; it works on a
- * copy of the table with 16-byte aligned rows made by this call in the context's scratch (K*M*528 bytes). */
+ * model) take the fast path: rows brought into LDS by a loader wave, searched by a decoder wave; it works on a
+ * compact copy of the table made by this call in the context's scratch (K*M*192 bytes: per row the 16 segment heads
+ * and the 64 entries of the four heaviest consecutive segments; other segments are read from `table` itself). */
 int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                     const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
                     int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
@@ -212,8 +213,8 @@ int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M,
 
 /* Same as mpc_rans_decode, for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): it calls no allocating routine.  It has no counterpart in the
- * reference.  The aligned table copy lives in a static device array of the library instead of context scratch:
- * L must be 257 and K*M at most 16384 rows (8.25 MiB per GPU, held until the process ends), otherwise MPC_EINVAL.
+ * reference.  The compact table copy lives in a static device array of the library instead of context scratch:
+ * L must be 257 and K*M at most 16384 rows (3 MiB per GPU, held until the process ends), otherwise MPC_EINVAL.
  * All calls on one GPU share that array: calls that overlap in time on one GPU (two streams, two contexts) race. */
 int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                             const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
