@@ -285,7 +285,8 @@ int launch_tr(mpc_ctx *ctx, const Params &p, int groups) {
 // image padded to 4 channels: 25 taps -> 8 k-steps, then the GDN mix), so a workgroup lives for only 8 + 2 NF steps and
 // what matters is that nothing in them waits: the whole 35 x 19 image patch of the 16 x 8 output tile is split into
 // fp16 hi/lo ONCE, when it is staged ([hi x4 | lo x4] = one 16-byte slot per pixel, column parities apart so that the
-// 16 lanes of a tile row read consecutive slots), the weights and gamma stream through the LDS-DMA ring, and two
+// 16 lanes of a tile row read consecutive slots), the weights and gamma stream through the LDS-DMA ring two steps
+// ahead of their use (a chunk is waited for one step after it was issued, never in the step that issued it), and two
 // workgroups share a CU so that one's prologue and 768-byte-per-pixel stores overlap the other's MFMAs.  A lane's
 // 8 k-values of a k-step are two whole pixels: taps 4S + 2h and 4S + 2h + 1.
 //
@@ -358,10 +359,11 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(104))) void 
         const int sec = rem / HOUT, r = rem - sec * HOUT;
         goff[q] = ks * WCH_F4 + sec * COUT + r;
     }
-    auto dma_chunk = [&](int c, int slot) {               // chunk of step c (steps past the end: the first again, unused)
-        const bool gdn = c >= KSTEPS && c < NSTEPS;
+    auto dma_chunk = [&](int c, int slot) {               // chunk of step c (no step past the last: nothing is issued)
+        if (c >= NSTEPS) return;
+        const bool gdn = c >= KSTEPS;
         const int g = c - KSTEPS, pass = g >= NF ? 1 : 0, kk = g - pass * NF;
-        const f4 *base = gdn ? gsrc + (int64_t)(2 * kk) * WCH_F4 + pass * HOUT : wsrc + (int64_t)(c < KSTEPS ? c : 0) * WCH_F4;
+        const f4 *base = gdn ? gsrc + (int64_t)(2 * kk) * WCH_F4 + pass * HOUT : wsrc + (int64_t)c * WCH_F4;
 #pragma unroll
         for (int q = 0; q < WPW; ++q) {
             const int piece = wave * WPW + q;
@@ -415,9 +417,14 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(104))) void 
 
     const f4 *bbase = patch + (2 * (2 * wave + (j >> 4))) * RGB_ROW + (j & 15);
     int slot = SLOT0;
-    // end of a step: the chunk issued in it has landed (observed), every wave has read the chunk of the step
-    auto step_end = [&]() {
-        dma_wait_last(wring + prev_slot(slot) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane);
+    // End of step t: the chunk of step t + 1 has landed (observed) -- it was issued a whole step earlier, at the top of
+    // step t - 1, so its latency lies behind a step's MFMAs; the chunk issued in THIS step (t + 2) stays in flight
+    // across the barrier -- and every wave has read the chunk of the step.
+    auto step_end = [&](int t) {
+        if (t + 1 < NSTEPS) {
+            void *watched = wring + next_slot(slot) * WCH_F4 + (wave * WPW + WPW - 1) * 64 + lane;
+            if (t + 2 < NSTEPS) dma_wait_last<WPW>(watched); else dma_wait_last<0>(watched);
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         slot = next_slot(slot);
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(104))) void 
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[f], 0, 0, 0);                                  \
             acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[f], 0, 0, 0);                                  \
         }                                                                                                              \
-        step_end();                                                                                                    \
+        step_end(S);                                                                                                   \
     }
     MPC_RGB_STEP(0) MPC_RGB_STEP(1) MPC_RGB_STEP(2) MPC_RGB_STEP(3)
     MPC_RGB_STEP(4) MPC_RGB_STEP(5) MPC_RGB_STEP(6) MPC_RGB_STEP(7)
@@ -499,12 +506,9 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(104))) void 
                 bl = nl;
                 if (s2 == 0) __builtin_amdgcn_sched_barrier(0);   // (the second k-step's operand reads stay behind the first's MFMAs: registers)
             }
-            step_end();
+            step_end(KSTEPS + pass * NF + kk);
         }
-        if (pass == 1) {
-            lds_dma_fence(wring);                        // the surplus pieces have landed before the whole LDS is reused
-            __syncthreads();
-        }
+        if (pass == 1) __syncthreads();                  // (no transfer is in flight: every chunk issued has been observed)
         MPC_STAMP(3 + pass)
         // ---- normalise and store this pass's HF tiles: y * (beta + norm)^(-1/2) -------------------------------------
         if (h == 0) ts_opix[j] = pvalid ? (long long)opix : -1ll;   // (in both passes: ring slot 0 has been written over in between)

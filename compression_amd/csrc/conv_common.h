@@ -53,8 +53,11 @@ __device__ __forceinline__ void dma_mark_last(void *lane_dst) {
     dma_marks_stored();
 }
 
+// KEEP: vector-memory operations of this wave that may stay in flight (the pieces of a YOUNGER batch, issued behind the
+// watched one: the counter retires in order, and the poll below is what proves the arrival anyway).
+template <int KEEP = 0>
 __device__ __forceinline__ void dma_wait_last(void *lane_dst) {
-    __builtin_amdgcn_s_waitcnt((0 & 15) | ((0 >> 4) << 14) | (7 << 4) | (15 << 8));               // vmcnt(0)
+    __builtin_amdgcn_s_waitcnt((KEEP & 15) | ((KEEP >> 4) << 14) | (7 << 4) | (15 << 8));         // vmcnt(KEEP)
     asm volatile("" ::: "memory");
 #ifdef MPC_NO_DMA_FENCE                                    // (measurement builds only: what the wait costs beyond vmcnt(0))
     return;
