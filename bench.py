@@ -423,8 +423,9 @@ def run_rank(args):
 
     testolina = args.arch.startswith("Testolina")
     if args.mode == "hp_codec":
-        # the hyperprior models: exact f32 analysis (h_a reads the unrounded latent), the default fp16 synthesis
-        model = ca.init_model(args.arch, dev, out_channel_N=192, out_channel_M=256)
+        # the hyperprior models: g_a / g_s arithmetic as for the Manypriors workloads (h_a reads g_a's unrounded fp32 latent)
+        model = ca.init_model(args.arch, dev, out_channel_N=192, out_channel_M=256, analysis_precision=args.analysis_precision,
+                              synthesis_precision=args.synthesis_precision)
         sd = synth.transform_weights(237, 192, 256, testolina=testolina)
         sd.update(synth.hyperprior_weights(239, 192, 256))
         model.load_state_dict(sd)
@@ -657,7 +658,7 @@ def run_rank(args):
         "metric": metric, "value": value, "unit": "megapixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "f16x3": "f16 hi/lo split x3 (fp32-grade), f32 accumulate"}["fp32" if args.mode == "hp_codec" else args.analysis_precision]
+        "dtype": {"fp32": "f32", "f16x3": "f16 hi/lo split x3 (fp32-grade), f32 accumulate"}[args.analysis_precision]
                  + " (g_a); " + {"fp32": "f32", "fp16": "f16, f32 accumulate"}[args.synthesis_precision] + " (g_s)",
         "data": "synthetic",
         "config": {"workload": f"config {args.config}: {CONFIGS[args.config]['what']} per GPU, {args.arch} N=192 M=256 K=64, "

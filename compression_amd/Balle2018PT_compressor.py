@@ -230,7 +230,10 @@ class Balle2018PTTFExp_ImageCompressor(abstract_model.AbstractHyperpriorImageCom
     def __init__(self, out_channel_N=192, out_channel_M=320, lossf="mse", device="cuda:0", entropy_coding=False, **kwargs):
         super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, lossf=lossf, device=device,
                          entropy_coding=entropy_coding, **kwargs)
-        self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        # analysis_precision: "fp32" (exact f32 MFMA, default) | "f16x3" (split-precision fp16 MFMA, fp32-grade: the same
+        # symbols up to rounding ties; h_a still reads the unrounded fp32 latent)
+        self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                    precision=kwargs.get("analysis_precision") or "fp32")
         self.Decoder = Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
                                      precision=kwargs.get("synthesis_precision", "fp16"))
         self.priorDecoder = SynthesisTFCodeExp_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)

@@ -63,8 +63,10 @@ class TestolinaHP_ImageCompressor(abstract_model.AbstractHyperpriorImageCompress
     def __init__(self, out_channel_N=192, out_channel_M=320, lossf="mse", device="cuda:0", entropy_coding=False, **kwargs):
         super().__init__(out_channel_N=out_channel_N, out_channel_M=out_channel_M, lossf=lossf, device=device,
                          entropy_coding=entropy_coding, **kwargs)
-        self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
-        self.Decoder = Testolina_Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
+        self.Encoder = Analysis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                    precision=kwargs.get("analysis_precision") or "fp32")
+        self.Decoder = Testolina_Synthesis_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M,
+                                               precision=kwargs.get("synthesis_precision") or "fp16")
         self.priorDecoder = SynthesisTFCodeExp_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
         self.priorEncoder = Analysis_prior_net(out_channel_N=out_channel_N, out_channel_M=out_channel_M)
 

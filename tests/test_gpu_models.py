@@ -319,6 +319,27 @@ def test_hyperprior_batch_round_trip_without_materialised_rows(dev):
     assert torch.equal(ys[2], y1) and torch.equal(zs[2], z1)
 
 
+def test_hyperprior_split_precision_analysis(dev, golden):
+    """analysis_precision="f16x3" on the hyperprior model: y symbols equal the reference's capture up to rounding ties
+    (<= 1e-5), z symbols exactly or in at most a few places (z = round(h_a(y)) reads the unrounded latent), and the codec
+    round trip still returns g_s(round(y))."""
+    import compression_amd as ca
+    g = golden("encode_hyperprior")
+    m = ca.init_model("Balle2018PTTFExp", dev, out_channel_N=N, out_channel_M=M, synthesis_precision="fp32",
+                      analysis_precision="f16x3")
+    m.load_state_dict(synth.hyperprior_state_dict(236, N, M))
+    m.eval()
+    x = synth.smooth_image(4, 1, 128, 192).to(dev)
+    ys, zs = m.encode(x, entropy_coding=False)
+    fy = (ys.cpu() != torch.from_numpy(g["y_sym"])).float().mean().item()
+    fz = (zs.cpu() != torch.from_numpy(g["z_sym"])).float().mean().item()
+    print(f"hyperprior, f16x3 analysis: {fy:.1e} of the y symbols and {fz:.1e} of the z symbols differ from the capture")
+    assert fy <= 1e-5 and fz <= 1e-3
+    bs = m.encode(x)
+    yq, _ = m.compress(x)
+    assert torch.equal(m.decode(bs), m.decode(yq))
+
+
 def test_testolina_hyperprior_codec_round_trip(dev):
     """TestolinaHP (hyperprior entropy model + the extended decoder): encode -> bytes -> decode returns exactly what
     its g_s makes of round(y), and the coded size is close to the model's own estimate."""
