@@ -488,7 +488,9 @@ def run_rank(args):
     pipe = None
     if args.mode == "codec" and not args.serial:
         from compression_amd.pipeline import CodecPipeline
-        pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis)
+        pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis,
+                             early_first_layer=os.environ.get("MPC_BENCH_EARLY_FIRST_LAYER", "0") == "1",
+                             decoder_behind=os.environ.get("MPC_BENCH_DECODER_BEHIND", "synthesis"))
     fpipe = None
     if args.mode == "forward" and not args.serial:
         from compression_amd.pipeline import ForwardPipeline

@@ -94,15 +94,33 @@ class Analysis_net(_FusedNet):
             t = l3(l2(l1(x4)))
         return l4(t, round_out=round_out, keep_unrounded=keep_unrounded)
 
-    def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False, events=None):
+    def forward_symbols(self, x4, min_feat, n_sym_values, n_clamped=None, keep_rounded=False, events=None, first_layer_on=None):
         """x4 -> (round(y) | None, int16 symbols NHWC, clamped count): quantisation and symbolisation run in the last
-        layer's epilogue.  events (a dict): receives "layer2_done" and "layer3_done", events recorded behind the second and the third layer."""
+        layer's epilogue.  events (a dict): receives "layer2_done" and "layer3_done", events recorded behind the second and the third layer.
+        first_layer_on = (stream, event | None): the first layer runs on that stream (x4 must be complete there), behind
+        the event, and the other layers on the current stream behind it: for a caller that lets the first layer, which
+        leaves half of the matrix pipe idle, start before the work queued on the current stream has ended."""
         l1, l2, l3, l4 = self.layers()
         split = self.precision == "f16x3"
         if split:
             self._check_split_range()
         kw = dict(out_split=True) if split else {}
-        t = l2(l1(x4, **kw), **kw)
+        if first_layer_on is None:
+            t = l1(x4, **kw)
+        else:
+            early, after = first_layer_on
+            main = torch.cuda.current_stream(x4.device)
+            with torch.cuda.stream(early):
+                if after is not None:
+                    early.wait_event(after)
+                t = l1(x4, **kw)
+                first_done = torch.cuda.Event()
+                first_done.record()
+            main.wait_event(first_done)
+            for part in (t if isinstance(t, (tuple, list)) else (t,)):
+                if isinstance(part, torch.Tensor):
+                    part.record_stream(main)
+        t = l2(t, **kw)
         if events is not None:
             events["layer2_done"] = torch.cuda.Event()
             events["layer2_done"].record()
@@ -154,15 +172,20 @@ class Synthesis_net(_FusedNet):
         return [(D, self.deconv1, 2, G, self.igdn1, False), (D, self.deconv2, 2, G, self.igdn2, False),
                 (D, self.deconv3, 2, G, self.igdn3, False), (D, self.deconv4, 2, _lib.MPC_ACT_NONE, None, False)]
 
-    def forward_nhwc(self, y, score_against=None):
+    def forward_nhwc(self, y, score_against=None, events=None):
         """y: NHWC fp32 latent -> NCHW fp32 image (unclamped).  With precision "fp16" (default) the four layers
         run on fp16-operand MFMA with fp16 activations: x_hat stays within 1e-2 of the fp32 result.
         score_against (an NCHW fp32 image): -> (clamp(x_hat, 0, 1), float64 [B] squared errors against it), from the
-        last layer's epilogue where that kernel exists, else from one more pass."""
+        last layer's epilogue where that kernel exists, else from one more pass.
+        events (a dict): receives "deconv2_done", recorded in front of the third transposed layer."""
         l1, l2, l3, l4 = self.layers()
         if self.precision == "fp16" and y.dtype != torch.float16:
             y = ops.f32_to_f16(y)
-        t = l3(l2(l1(y)))
+        t = l2(l1(y))
+        if events is not None:
+            events["deconv2_done"] = torch.cuda.Event()
+            events["deconv2_done"].record()
+        t = l3(t)
         if score_against is None:
             return l4(t, nchw_out=True)
         return _scored_last_layer(l4, t, score_against)

@@ -356,11 +356,12 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
             return job["sym"].view(job["B"], -1), job["idx"].view(job["B"], -1), job["h"], job["w"]
         return self.encode_batch_finish(job)
 
-    def encode_batch_begin(self, input_image, entropy_coding=True, input_nhwc=None):
+    def encode_batch_begin(self, input_image, entropy_coding=True, input_nhwc=None, first_layer_on=None):
         """Enqueues the encoder's kernels on the current stream and returns at once.  -> a job for encode_batch_finish;
         job["transforms_done"] is an event recorded behind g_a (what a pipelined caller orders other MFMA work after).
         input_nhwc: the image already in the first layer's layout (ops.nchw_to_nhwc(x, 4)), for a caller that made it
-        ahead of time on another stream and has ordered the current stream behind it."""
+        ahead of time on another stream and has ordered the current stream behind it.  first_layer_on = (stream,
+        event | None): see Analysis_net.forward_symbols (input_nhwc must then be complete on that stream)."""
         self._ensure_tables()
         x = input_image.contiguous()
         B, M = x.shape[0], self.out_channel_M
@@ -372,7 +373,8 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         geom_d, nclamp_d = meta[3 * B:3 * B + 2], meta[3 * B + 2:3 * B + 3]
         events = {}
         x4 = input_nhwc if input_nhwc is not None else ops.nchw_to_nhwc(x, 4)
-        _, sym4, _ = self.Encoder.forward_symbols(x4, self.min_feat, self._n_targets() - 1, nclamp_d, events=events)
+        _, sym4, _ = self.Encoder.forward_symbols(x4, self.min_feat, self._n_targets() - 1, nclamp_d, events=events,
+                                                  first_layer_on=first_layer_on)
         transforms_done = torch.cuda.Event()
         transforms_done.record()
         if SYNTHESIS_MAY_START_BEHIND_LAYER in (2, 3):
@@ -488,17 +490,18 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         done.record()
         return dict(B=B, h=h, w=w, sym=sym, latent=direct, st_host=st_host, done=done, recon=None, keep=(buf, idx32, status))
 
-    def decode_batch_synthesis(self, job, score_against=None):
+    def decode_batch_synthesis(self, job, score_against=None, events=None):
         """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on).  score_against (the
         batch's original, NCHW fp32): the job's reconstruction is then clamp(x_hat, 0, 1) and job["sse"] holds the
-        per-image squared errors against it (float64 [B] on the device), both from the last layer's epilogue."""
+        per-image squared errors against it (float64 [B] on the device), both from the last layer's epilogue.
+        events (a dict): receives "deconv2_done" (see Synthesis_net.forward_nhwc)."""
         B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
         y = job["sym"].view(B, h, w, M)
         y = y if job["latent"] else self.Decoder.latent_from_symbols(y, self.min_feat, self.q_intv)
         if score_against is None:
-            job["recon"] = self.Decoder.forward_nhwc(y)
+            job["recon"] = self.Decoder.forward_nhwc(y, events=events)
         else:
-            job["recon"], job["sse"] = self.Decoder.forward_nhwc(y, score_against=score_against)
+            job["recon"], job["sse"] = self.Decoder.forward_nhwc(y, score_against=score_against, events=events)
         _mark("dec:enqueued")
         return job
 

@@ -5,18 +5,27 @@ chains) -> byte strings on the host -> rANS decoder (latency-bound) -> g_s (MFMA
 other, the GPU idles through the latency-bound parts and the host round trip in the middle: a fifth of the step.  The
 batches are independent, so this driver keeps two in flight, each on its own stream, and orders the work so that
 
-    stream of batch n     : g_a(n) | competition, encoder(n) | host: bytes of n | ........ wait ....... | decoder(n) | g_s(n)
-    stream of batch n - 1 : decoder(n-1) | wait | g_s(n-1) .....................| g_a(n+1) ............................
+    stream of batch n     : g_a(n) | competition, encoder(n) | ............ wait ............ | decoder(n) | g_s(n)
+    stream of batch n - 1 : decoder(n-1) | wait | g_s(n-1) ..................| g_a(n+1) ............................
+    host                  : enqueue g_a(n), encoder(n) | fetch the bytes of n-1 | enqueue decoder(n-1), g_s(n-1) | n+1 ...
 
 the bulk of the two transforms never runs side by side (g_s(n-1) waits for an event behind the third layer of g_a(n),
 manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER, so only the last analysis layer -- too small to fill the chip --
 shares the CUs with the first transposed layers: +1.5 %; g_a(n+1) is enqueued behind g_s(n-1) on the same stream.  Two
 MFMA-bound kernels that share the CUs for long only slow each other: measured 12 % worse than no pipelining at all),
 the encoder runs beside g_s(n-1), and the decoder of a batch, held back until the g_s before it has ended, beside the
-first layer of the next g_a (both kernels are built to fit a SIMD together: 2 x 208 + 2 x 48 registers).  Every batch still goes
-encode -> bytes on the host -> decode; only the order in which the host enqueues the phases changes
-(encode_batch_begin/finish, decode_batch_begin/synthesis/finish of the model).  The reference codes one image at a
-time on one stream (src/compression/tests.py:439-460); it has no counterpart of this driver.
+first layer of the next g_a (both kernels are built to fit a SIMD together: 2 x 208 + 2 x 48 registers).  The host
+fetches a batch's byte strings one call after it enqueued that batch's encoder, so it never waits for the GPU with
+nothing queued behind.  Every batch still goes encode -> bytes on the host -> decode; only the order in which the
+host enqueues the phases changes (encode_batch_begin/finish, decode_batch_begin/synthesis/finish of the model).
+
+early_first_layer=True additionally starts the first layer of g_a(n+1) beside the third layer of g_s(n-1) (256 + 208
+registers fit a SIMD, and alone each kernel keeps the matrix pipe under half busy).  Measured, the pair then takes
+2.55 ms instead of 1.43 + 1.24 ms one after the other, and the decoder, which loses its place beside the first
+layer, costs the second layer 0.28 ms: 1.3-2.5 % slower over the whole step, hence off by default.
+
+The reference codes one image at a time on one stream (src/compression/tests.py:439-460); it has no counterpart of
+this driver.
 """
 import torch
 
@@ -24,17 +33,26 @@ from . import ops
 
 
 class CodecPipeline:
-    def __init__(self, model, device, after_synthesis=None):
+    def __init__(self, model, device, after_synthesis=None, early_first_layer=False, decoder_behind="synthesis"):
         """after_synthesis(job, strings, tag) -> anything: called right behind g_s with the batch's stream current
         (job["recon"]: the reconstruction; with a target given to submit() it is clamped and job["sse"] holds the
-        per-image squared errors); e.g. the batch's statistics.  Its value comes back with the result."""
+        per-image squared errors); e.g. the batch's statistics.  Its value comes back with the result.
+        early_first_layer: the first layer of g_a(n+1) runs beside the third layer of g_s(n-1) (see the module's text).
+        decoder_behind: what the decoder of a batch waits for, "synthesis" (the end of the g_s before it) or "deconv2"
+        (the second layer of that g_s)."""
+        if decoder_behind not in ("synthesis", "deconv2"):
+            raise ValueError("decoder_behind: 'synthesis' or 'deconv2'")
         self.model = model
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        self.early = torch.cuda.Stream(self.device)   # image layout and first layer of every batch
+        self.early_first_layer = early_first_layer
+        self.decoder_behind = decoder_behind
         self.after_synthesis = after_synthesis
-        self.pending = None          # (byte strings, idx, h, w, stream, tag, target) of the batch that is encoded and not yet decoded
+        self.encoding = None         # (encoder job, stream, tag, target) of the batch whose byte strings are not fetched yet
         self.count = 0
         self.synthesis_done = None   # event behind the g_s (and hook) enqueued last
+        self.deconv2_done = None     # event in front of the third layer of that g_s
         for s in self.streams:       # whatever produced the inputs on the caller's stream comes first
             s.wait_stream(torch.cuda.current_stream(self.device))
 
@@ -42,42 +60,48 @@ class CodecPipeline:
         """Enqueues decoder and g_s of the batch whose byte strings are on the host, each behind its event."""
         strings, idx, h, w, stream, tag, target = undecoded
         with torch.cuda.stream(stream):
-            if self.synthesis_done is not None:
-                stream.wait_event(self.synthesis_done)           # decoder(n-1) behind g_s(n-2): beside the first layer of g_a(n)
+            held_by = self.synthesis_done if self.decoder_behind == "synthesis" else self.deconv2_done
+            if held_by is not None:
+                stream.wait_event(held_by)
             job = self.model.decode_batch_begin(strings, idx, h, w)
             if transforms_done is not None:
-                stream.wait_event(transforms_done)               # g_s(n-1) behind g_a(n)
-            self.model.decode_batch_synthesis(job, score_against=target)
+                stream.wait_event(transforms_done)               # g_s(n-1) behind the third layer of g_a(n)
+            events = {}
+            self.model.decode_batch_synthesis(job, score_against=target, events=events)
             extra = self.after_synthesis(job, strings, tag) if self.after_synthesis is not None else None
             self.synthesis_done = torch.cuda.Event()
             self.synthesis_done.record()
+            self.deconv2_done = events.get("deconv2_done")
         return job, stream, strings, tag, extra
 
-    def submit(self, x, tag=None, target=None):
-        """Encodes batch n (its byte strings reach the host inside this call) and decodes batch n - 1.  target: the
-        image batch n's reconstruction is to be scored against (see decode_batch_synthesis).  -> None for the first
-        batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1; x_hat is complete on the stream
-        `result_stream` (the caller's next use must be ordered behind it)."""
-        stream = self.streams[self.count & 1]
-        idle = self.streams[(self.count + 1) & 1]                # (its batch's encoder has ended: encode_batch_finish waited)
-        self.count += 1
-        # The image goes to the first layer's layout on the idle stream, beside the g_s that `stream` is still running:
-        # enqueued on `stream` the 45 us pass would sit between that g_s and this batch's g_a, on the critical path.
-        idle.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(idle):
-            x4 = ops.nchw_to_nhwc(x.contiguous(), 4)
-            laid_out = torch.cuda.Event()
-            laid_out.record()
-        x4.record_stream(stream)
-        with torch.cuda.stream(stream):
-            stream.wait_event(laid_out)
-            enc = self.model.encode_batch_begin(x, input_nhwc=x4)
-        done = None
-        if self.pending is not None:
-            done = self._decode(self.pending, enc["transforms_done"])
+    def _fetch_and_decode(self, transforms_done):
+        enc, stream, tag, target = self.encoding
+        self.encoding = None
         with torch.cuda.stream(stream):
             strings, idx, h, w = self.model.encode_batch_finish(enc)
-        self.pending = (strings, idx, h, w, stream, tag, target)
+        return self._decode((strings, idx, h, w, stream, tag, target), transforms_done)
+
+    def submit(self, x, tag=None, target=None):
+        """Enqueues the encoder of batch n, then fetches the byte strings of batch n - 1 and enqueues its decoder and
+        g_s.  target: the image batch n's reconstruction is to be scored against (see decode_batch_synthesis).  ->
+        None for the first batch, else (byte strings, x_hat, after_synthesis' value, tag) of batch n - 1; x_hat is
+        complete on the stream `result_stream` (the caller's next use must be ordered behind it)."""
+        stream = self.streams[self.count & 1]
+        self.count += 1
+        # The image goes to the first layer's layout on a stream of its own, beside whatever runs: enqueued on `stream`
+        # the 45 us pass would sit between the g_s that stream still runs and this batch's g_a, on the critical path.
+        self.early.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.early):
+            x4 = ops.nchw_to_nhwc(x.contiguous(), 4)
+        with torch.cuda.stream(stream):
+            if self.early_first_layer:
+                enc = self.model.encode_batch_begin(x, input_nhwc=x4, first_layer_on=(self.early, self.deconv2_done))
+            else:
+                stream.wait_stream(self.early)
+                x4.record_stream(stream)
+                enc = self.model.encode_batch_begin(x, input_nhwc=x4)
+        done = self._fetch_and_decode(enc["transforms_done"]) if self.encoding is not None else None
+        self.encoding = (enc, stream, tag, target)
         return self._finish(done)
 
     def _finish(self, done):
@@ -91,14 +115,12 @@ class CodecPipeline:
 
     def flush(self):
         """Decodes the batch still in flight (-> its result, or None if there is none)."""
-        if self.pending is None:
+        if self.encoding is None:
             return None
-        done = self._decode(self.pending, None)
-        self.pending = None
-        return self._finish(done)
+        return self._finish(self._fetch_and_decode(None))
 
     def synchronize(self):
-        for s in self.streams:
+        for s in self.streams + [self.early]:
             s.synchronize()
 
 

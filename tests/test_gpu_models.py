@@ -491,10 +491,12 @@ def test_timing_analysis_keys(model_fp16, dev):
     assert model_fp16.decode([bitstream, indices, h, w]).shape == (1, 3, 128, 192)
 
 
-def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev):
+@pytest.mark.parametrize("order", [dict(), dict(early_first_layer=True), dict(early_first_layer=True, decoder_behind="deconv2")],
+                         ids=["default", "early_first_layer", "early_first_layer_and_decoder"])
+def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev, order):
     """Two batches in flight on two streams (CodecPipeline) give, batch for batch, the byte strings and the
     reconstruction of encode_batch -> decode_batch run one after the other, at a size with several workgroups per CU
-    so that the phases really overlap."""
+    so that the phases really overlap; in every order of the phases the driver offers."""
     from compression_amd import ops
     from compression_amd.pipeline import CodecPipeline
     batches = [synth.rand_image(300 + i, 6, 256, 384).to(dev) for i in range(5)]
@@ -507,7 +509,7 @@ def test_codec_pipeline_matches_one_batch_at_a_time(model_fp16, dev):
     def score(job, strings, tag):
         return ops.clamp_sse_per_image(job["recon"], batches[tag])[1]
 
-    pipe = CodecPipeline(model_fp16, dev, after_synthesis=score)
+    pipe = CodecPipeline(model_fp16, dev, after_synthesis=score, **order)
     got = []
     for rep in range(2):                                   # the second round reuses every staging buffer
         for i, x in enumerate(batches):
