@@ -79,10 +79,30 @@ static inline int64_t mpc_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // float -> int16 the way a vectorised x86 cast does it: through int32, keeping the low 16 bits.
 __device__ __forceinline__ int16_t mpc_wrap_i16(float v) { return (int16_t)(uint16_t)((uint32_t)(int32_t)v & 0xffffu); }
 
+// expm1(q) for q <= 0 in double, to about 2^-40 relative: q = k ln 2 + r with |r| <= ln 2 / 2, the Taylor polynomial of
+// expm1(r) to r^11 evaluated pairwise (a dependent chain of 12 operations where the general routine has several
+// times that: the coder's decoder waits for exactly this chain once per symbol), 2^k (1 + p) - 1 as one fma.  Rounded
+// to float it equals the library's expm1 rounded to float for every float argument q <= 0
+// (tools/micro/expm1_check.hip walks all 2^31 of them).  NaN stays NaN; below -40 the result is -1 in double.
+__device__ __forceinline__ double mpc_expm1_nonpos(double q) {
+    if (!(q > -40.0)) return q != q ? q : -1.0;
+    const double k = rint(q * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, q);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = fma(r, 1.0 / 6.0, 0.5), a1 = fma(r, 1.0 / 120.0, 1.0 / 24.0), a2 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
+    const double a3 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0), a4 = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2);
+    const double poly = fma(a4, r8, fma(b1, r4, b0));
+    const double p = fma(r2, poly, r);
+    const double s = ldexp(1.0, (int)k);
+    return fma(s, p, s - 1.0);
+}
+
 // torch.distributions.Laplace(0, scale).cdf(x) = 0.5 - 0.5 * sign(x) * expm1(-|x| / scale)
 __device__ __forceinline__ float mpc_laplace_cdf(float x, float scale) {
     float sg = (x > 0.0f) ? 0.5f : ((x < 0.0f) ? -0.5f : 0.0f);
-    float em = (float)expm1((double)__fdiv_rn(-fabsf(x), scale));
+    float em = (float)mpc_expm1_nonpos((double)__fdiv_rn(-fabsf(x), scale));
     return __fsub_rn(0.5f, __fmul_rn(sg, em));
 }
 

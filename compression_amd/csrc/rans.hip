@@ -375,23 +375,43 @@ __global__ __launch_bounds__(256) void decode_streams_kernel(Geometry g, const u
     if (err && t == 0) atomicMin(&status[img], err);
 }
 
-// Decoder for per-element Laplace(0, sigma) rows, S = L - 1 <= 256 symbols.  Nothing is read per symbol but its sigma
-// (4 bytes, fetched 16 symbols at a time, one block ahead): the 16-lane group of a stream finds the symbol with the
-// two-level search of the fast decoder below, evaluating the row entries it looks at -- lane t the segment head
-// entry(16 t), computed a symbol ahead because it depends on sigma only, then entry(16 seg + t) of the segment the
-// state falls into.  Entries at index >= S count as 2^16, as in count_le.  The entries come from
-// mpc_laplace_row_entry, the function the encoder side uses, so both sides see the same integers.
+// Decoder for per-element Laplace(0, sigma) rows, S = L - 1 <= 256 symbols.  Nothing is read per symbol but its sigma;
+// the row entries the search looks at are evaluated (mpc_laplace_row_entry, the function the encoder side uses, so both
+// sides see the same integers; entries at index >= S count as 2^16, as in count_le).
+//
+// One wave decodes one stream.  The serial chain state -> symbol -> state is all there is to a stream, so the kernel
+// is built to keep that chain short:
+//   * whatever depends on sigma only is evaluated ahead of the chain, four symbols per pass: the 64 lanes are 4 symbols
+//     x 16 entries.  Which 16 entries follows the row's shape.  scale <= LAPLACE_WINDOW_MAX_SCALE: entry(w0 + t), the
+//     window round the mode (values -7 .. +7 for the standard table); a state that falls between the first and the last
+//     of them (all but exp(-7.5 / scale) of the states: 99.8 % at scale 1.2, 85 % at 4) is decoded with no evaluation on
+//     the chain.  Wider rows: the segment heads entry(16 t); the chain then evaluates entry(16 seg + t) of the segment
+//     the state falls into (the two-level search of the fast decoder below).  A narrow row whose state falls outside
+//     the window does the two-level search with both evaluations on the chain.
+//   * the coder state, the slot, the symbol and the interval live in scalar registers: a ballot gives the count, the
+//     two interval ends are read from the lanes that hold them (v_readlane), the state update is scalar arithmetic.
+//   * nothing on the chain waits for memory: the stream's words and the sigmas are held 64 at a time in a register
+//     (lane l: element base + l), the following 64 are loaded while those are used; the next word / the scales of the
+//     next four symbols are taken out of the register by lane index.  Symbols are stored 64 at a time.
+constexpr float LAPLACE_WINDOW_MAX_SCALE = 4.0f;
+constexpr int LAPLACE_WAVES_PER_BLOCK = 4;
+
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t lane) {      // lane: the same in every lane
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
 __global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g, const float *__restrict__ sigma, float first,
                                                                       float factor, const uint8_t *__restrict__ in,
                                                                       size_t in_stride, const uint64_t *__restrict__ nbytes,
                                                                       int16_t *__restrict__ sym_out,
                                                                       int32_t *__restrict__ status) {
-    const int lane = threadIdx.x & 63;
-    const int t = lane & (GROUP - 1);
-    const int gshift = lane & ~(GROUP - 1);
-    const int64_t gid = (int64_t)blockIdx.x * GROUPS_PER_BLOCK + (threadIdx.x / GROUP);
+    const uint32_t lane = threadIdx.x & 63;
+    const int t = (int)(lane & 15);
+    // (the wave's index through readfirstlane: the compiler then knows that everything derived from it is the same in
+    // all lanes and keeps it, the coder state included, in scalar registers)
+    const int64_t gid = (int64_t)blockIdx.x * LAPLACE_WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t G = (int64_t)g.n_images * g.n_streams;
-    if (gid >= G) return;                                   // whole groups leave together
+    if (gid >= G) return;                                   // whole waves leave together
     const int img = (int)(gid / g.n_streams);
     const uint32_t stream = (uint32_t)(gid % g.n_streams);
     const uint8_t *src = in + (size_t)img * in_stride;
@@ -407,20 +427,26 @@ __global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g,
     if (!err) {
         const uint16_t *lens = (const uint16_t *)(src + 16);
         uint32_t acc = 0;
-        for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
-        off += 2 * group_sum(acc);
+        for (uint32_t j = lane; j < stream; j += 64) acc += lens[j];
+        acc = group_sum(acc);
+        acc = lane_value(acc, 0) + lane_value(acc, 16) + lane_value(acc, 32) + lane_value(acc, 48);
+        off += 2 * acc;
         my_len = lens[stream];
         if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
     }
     if (err) {
-        if (t == 0) atomicMin(&status[img], err);
+        if (lane == 0) atomicMin(&status[img], err);
         return;
     }
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    my_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_len);
     const uint16_t *words = (const uint16_t *)(src + off);
-    const uint16_t *wend = words + my_len;
-    uint32_t x = (uint32_t)words[0] | ((uint32_t)words[1] << 16);
-    const uint16_t *wp = words + 2;
-    uint32_t wnext = (wp < wend) ? *wp : 0;                 // next renormalisation word, loaded ahead
+    // (indices clamped, not guarded: a guarded load is waited for where the guard ends; what lies past the end is never used)
+    auto load_words = [&](uint32_t base) -> uint32_t { return (uint32_t)words[min(base + lane, my_len - 1)]; };
+    uint32_t wbuf = load_words(0), wbuf_nx = load_words(64);
+    uint32_t x = lane_value(wbuf, 0) | (lane_value(wbuf, 1) << 16);
+    uint32_t wi = 2;                                        // words taken so far
+    uint32_t wnext = lane_value(wbuf, 2);                   // (past the end: never used, a renormalisation there is an error)
 
     const uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
     const uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
@@ -429,48 +455,79 @@ __global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g,
     const float *sg = sigma + (int64_t)img * g.n_symbols + b;
     int16_t *dst = sym_out + (int64_t)img * g.n_symbols + b;
     auto entry = [&](float scale, int s) -> uint32_t { return s < S ? mpc_laplace_row_entry(scale, first, s, factor) : 0x10000u; };
-    auto block_scale = [&](uint32_t first_sym) { return first_sym + t < len ? mpc_laplace_scale(sg[first_sym + t]) : 1.0f; };
+    auto load_sigmas = [&](uint32_t base) -> float { return len ? sg[min(base + lane, len - 1)] : 1.0f; };
+    // first entry of the window round the mode: the symbol that holds the value 0 is -first - 0.5
+    const int w0 = max(0, min((int)rintf(-first - 0.5f) - 7, S - 15));
 
-    float scales = block_scale(0), scales_nx = 1.0f;        // lane t: symbols 16 q + t of the current / next block
-    uint32_t heads = entry(__shfl(scales, 0, GROUP), 16 * t);
+    float sbuf = load_sigmas(0), sbuf_nx = load_sigmas(64);
+    // lane (u, t) of a pass: symbol n0 + u; what it holds of that symbol's row, and the symbol's scale
+    auto ahead = [&](uint32_t n0, float &scale_out) -> uint32_t {
+        const float raw = __shfl(sbuf, (int)((n0 & 63) + (lane >> 4)), 64);
+        const float scale = mpc_laplace_scale(raw);
+        scale_out = scale;
+        return entry(scale, scale <= LAPLACE_WINDOW_MAX_SCALE ? w0 + t : 16 * t);
+    };
+    float scale_v = 1.0f, scale_nx = 1.0f;
+    uint32_t pre = ahead(0, scale_v);
     uint32_t mysym = 0;
-    for (uint32_t n = 0; n < len; ++n) {
-        const int q = (int)(n & 15);
-        if (q == 0) scales_nx = block_scale(n + 16);
-        const float scale = __shfl(scales, q, GROUP);
-        // the next symbol's segment heads: off the chain of the coder state
-        const float scale_nx = q == 15 ? __shfl(scales_nx, 0, GROUP) : __shfl(scales, (q + 1) & 15, GROUP);
-        const uint32_t heads_nx = entry(scale_nx, 16 * t);
-        // ---- the chain: state -> segment -> entry -> new state ----
-        const uint32_t slot = x & 0xffffu;
-        const uint32_t seg_cnt = __popc((uint32_t)(__ballot(heads <= slot) >> gshift) & 0xffffu);
-        const int seg = seg_cnt ? (int)seg_cnt - 1 : 0;
-        const uint32_t ent = entry(scale, 16 * seg + t);
-        const uint32_t in_seg = __popc((uint32_t)(__ballot(ent <= slot) >> gshift) & 0xffffu);
-        if (seg_cnt == 0 || in_seg == 0) { err = -24; break; }          // slot below the row's first entry: corrupt stream
-        const int s = 16 * seg + (int)in_seg - 1;
-        const uint32_t start = (uint32_t)__shfl((int)ent, (int)in_seg - 1, GROUP);
-        const uint32_t end_in = (uint32_t)__shfl((int)ent, (int)in_seg & 15, GROUP);
-        const uint32_t end_hd = (uint32_t)__shfl((int)heads, (seg + 1) & 15, GROUP);
-        const uint32_t end = in_seg < 16 ? end_in : (seg == 15 ? 0x10000u : end_hd);
-        x = (end - start) * (x >> 16) + slot - start;
-        if (x < RANS_L) {
-            if (wp >= wend) { err = -25; break; }
-            x = (x << 16) | wnext;
-            ++wp;
-            wnext = (wp < wend) ? *wp : 0;
+    for (uint32_t n0 = 0; n0 < len && !err; n0 += 4) {
+        // ---- ahead of the chain: the next four symbols ----
+        if (((n0 + 4) & 63) == 0) {
+            sbuf = sbuf_nx;
+            sbuf_nx = load_sigmas(n0 + 4 + 64);
         }
-        // ---- off the chain: symbols are written 16 at a time, one per lane ----
-        if (t == q) mysym = (uint32_t)s;
-        if (q == 15 || n + 1 == len) {
-            const uint32_t firstn = n & ~15u;
-            if (firstn + t <= n) dst[firstn + t] = decoded_value(g, (int)mysym);
+        const uint32_t pre_nx = ahead(n0 + 4, scale_nx);
+        const uint64_t narrow = __ballot(scale_v <= LAPLACE_WINDOW_MAX_SCALE);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t n = n0 + u;
+            if (n >= len) break;
+            // ---- the chain: state -> symbol -> new state, in scalar registers ----
+            const uint32_t slot = x & 0xffffu;
+            const uint32_t cnt = __popc((uint32_t)(__ballot(pre <= slot) >> (16 * u)) & 0xffffu);
+            const bool window = (narrow >> (16 * u)) & 1;
+            uint32_t sym, start, end;
+            if (window && cnt >= 1 && cnt <= 15) {
+                sym = (uint32_t)w0 + cnt - 1;
+                start = lane_value(pre, 16 * u + cnt - 1);
+                end = lane_value(pre, 16 * u + cnt);
+            } else {
+                const float scale = __uint_as_float(lane_value(__float_as_uint(scale_v), 16 * u));
+                uint32_t seg_cnt = cnt;
+                if (window) seg_cnt = __popc((uint32_t)__ballot(entry(scale, 16 * t) <= slot) & 0xffffu);
+                if (seg_cnt == 0) { err = -24; break; }                 // slot below the row's first entry: corrupt stream
+                const uint32_t seg = seg_cnt - 1;
+                // lanes 0..16: the segment's entries and the head of the next one (2^16 behind the row's end)
+                const uint32_t ent = entry(scale, (int)(16 * seg + lane));
+                const uint32_t in_seg = __popc((uint32_t)__ballot(ent <= slot) & 0xffffu);
+                if (in_seg == 0) { err = -24; break; }
+                sym = 16 * seg + in_seg - 1;
+                start = lane_value(ent, in_seg - 1);
+                end = lane_value(ent, in_seg);
+            }
+            x = (end - start) * (x >> 16) + slot - start;
+            if (x < RANS_L) {
+                if (wi >= my_len) { err = -25; break; }
+                x = (x << 16) | wnext;
+                ++wi;
+                if ((wi & 63) == 0) {
+                    wbuf = wbuf_nx;
+                    wbuf_nx = load_words(wi + 64);
+                }
+                wnext = lane_value(wbuf, wi & 63);
+            }
+            // ---- off the chain: symbols are stored 64 at a time, one per lane ----
+            if (lane == (n & 63)) mysym = sym;
+            if ((n & 63) == 63 || n + 1 == len) {
+                const uint32_t base = n & ~63u;
+                if (base + lane <= n) dst[base + lane] = decoded_value(g, (int)mysym);
+            }
         }
-        heads = heads_nx;
-        if (q == 15) scales = scales_nx;
+        pre = pre_nx;
+        scale_v = scale_nx;
     }
-    if (!err && (x != RANS_L || wp != wend)) err = -26;
-    if (err && t == 0) atomicMin(&status[img], err);
+    if (!err && (x != RANS_L || wi != my_len)) err = -26;
+    if (err && lane == 0) atomicMin(&status[img], err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1054,7 +1111,7 @@ int mpc_rans_decode_laplace(mpc_ctx *ctx, const float *sigma, float first_target
     const int64_t G = (int64_t)g.n_images * g.n_streams;
     const float factor = (float)(1 << precision) - (float)(L - 1);
     MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
-    decode_streams_laplace_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
+    decode_streams_laplace_kernel<<<dim3((unsigned)mpc_cdiv(G, LAPLACE_WAVES_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
         g, sigma, first_target, factor, in, in_stride, nbytes_dev, sym_out, status_dev);
     MPC_CHECK_LAUNCH(ctx, "rans decode_streams_laplace");
     return MPC_OK;
