@@ -65,9 +65,9 @@ CONFIGS = {
             what="full codec on one 3840x2160 image"),
     5: dict(arch="ManyPriors_DC", batch=8, height=1024, width=1024, mode="codec", data="noisy",
             what="JDC full codec on 8 noisy 1024x1024 images"),
-    6: dict(arch="TestolinaHP", batch=8, height=512, width=768, mode="hp_codec", data="smooth",
+    6: dict(arch="TestolinaHP", batch=24, height=512, width=768, mode="hp_codec", data="smooth",
             what="hyperprior full codec (encode_batch -> bytes -> decode_batch, main stream under per-element Laplace rows) "
-                 "on 8 x 768x512 images"),
+                 "on 24 x 768x512 images"),
 }
 # sources whose change invalidates the committed counter passes of the dominant kernel
 TRAFFIC_SOURCES = ("compression_amd/csrc/conv5s2_patch_x3.hip", "compression_amd/csrc/conv_x3_epilogue.h",

@@ -196,7 +196,9 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
                                                  self.precision, est)
         n_zloc = sym_z.numel() // (B * N)
         zidx = torch.zeros(B * n_zloc, dtype=torch.int32, device=x.device)
-        zstrs = ops.rans_encode_to_bytes(self._z_table(), zidx, sym_z, B, float(n_zloc * N))
+        # the z string is a hundredth of the image: its streams are budgeted against the image's bytes, not its own
+        # (a handful of streams would make its two coders the longest serial chains of the whole codec)
+        zstrs = ops.rans_encode_to_bytes(self._z_table(), zidx, sym_z, B, est + float(n_zloc * N), budget=ops.MRS1_STREAM_BUDGET / 2)
         return [[mains[i], zstrs[i], H, W] for i in range(B)]
 
     def encode(self, input_image, entropy_coding=True):

@@ -83,9 +83,10 @@ __device__ __forceinline__ int16_t mpc_wrap_i16(float v) { return (int16_t)(uint
 // expm1(r) to r^11 evaluated pairwise (a dependent chain of 12 operations where the general routine has several
 // times that: the coder's decoder waits for exactly this chain once per symbol), 2^k (1 + p) - 1 as one fma.  Rounded
 // to float it equals the library's expm1 rounded to float for every float argument q <= 0
-// (tools/micro/expm1_check.hip walks all 2^31 of them).  NaN stays NaN; below -40 the result is -1 in double.
+// (tools/micro/expm1_check.hip walks all 2^31 of them).  NaN stays NaN; below -40 the result is -1 in double (the
+// argument is clamped there, without a branch: exp(-40) is far below half a unit in the last place of 1).
 __device__ __forceinline__ double mpc_expm1_nonpos(double q) {
-    if (!(q > -40.0)) return q != q ? q : -1.0;
+    q = q < -40.0 ? -40.0 : q;
     const double k = rint(q * 1.4426950408889634074);
     double r = fma(k, -6.93147180369123816490e-01, q);
     r = fma(k, -1.90821492927058770002e-10, r);

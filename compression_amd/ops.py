@@ -466,11 +466,12 @@ def avg_pool2(x: torch.Tensor) -> torch.Tensor:
 
 
 def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_images: int,
-                         est_bytes_per_image: float) -> List[bytes]:
-    """Codes n_images equally shaped images and returns their MRS1 containers as byte strings."""
+                         est_bytes_per_image: float, budget: float = 0.004) -> List[bytes]:
+    """Codes n_images equally shaped images and returns their MRS1 containers as byte strings.  The stream count is
+    choose_streams(n_loc, M, est_bytes_per_image, budget)."""
     K, M, L = table.shape
     n_loc = idx.numel() // n_images
-    n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image)
+    n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image, budget)
     out, nbytes, status = rans_encode(table, idx.reshape(-1), sym.reshape(-1), n_images, n_streams, lps)
     meta = torch.cat([nbytes, status.to(torch.int64)]).cpu().tolist()
     nb, st = meta[:n_images], meta[n_images:]
