@@ -18,11 +18,11 @@
 // possible.
 #include "mpc_internal.h"
 
-// Scratch of the allocation-free decode entry point: the compact copy of the CDF table (192 bytes per row, see the fast
-// decoder below), at most NOALLOC_MAX_ROWS rows (the standard model has K*M = 64*256 of them) = 3 MiB per GPU, held until
+// Scratch of the allocation-free decode entry point: the compact copy of the CDF table (256 bytes per row, see the fast
+// decoder below), at most NOALLOC_MAX_ROWS rows (the standard model has K*M = 64*256 of them) = 4 MiB per GPU, held until
 // the process ends.  In host code `scratch` is only a handle for hipGetSymbolAddress; kernels get the per-device address.
 constexpr int NOALLOC_MAX_ROWS = 64 * 256;
-constexpr int CROW = 96;                   // 16-bit entries of a compact row: 16 x (head, w0), then the 64 window entries (192 bytes)
+constexpr int CROW = 128;                  // 16-bit halves of a compact row: 64 words of (window entry | head or w0 << 16), 256 bytes
 constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)NOALLOC_MAX_ROWS * CROW * sizeof(uint16_t);
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 static void *static_scratch_ptr[MPC_MAX_DEVICES] = {};
@@ -539,285 +539,231 @@ __global__ __launch_bounds__(256) void decode_streams_laplace_kernel(Geometry g,
 // ---------------------------------------------------------------------------------------------
 // Fast decoder for 256-symbol rows (L = 257, the standard table).
 //
-// The serial chain of a stream is: state -> symbol search in the symbol's CDF row -> new state.  The row of every
-// symbol is known in advance (prior index of the location, channel), so a loader wave brings rows into an LDS ring a
-// few symbols ahead of their use and the coder state only ever waits on LDS.
+// The serial chain of a stream is: state -> symbol search in the symbol's CDF row -> new state; a stream is nothing
+// but that chain, a few thousand symbols long, and the decoder's time is the time of one chain.  One wave decodes one
+// stream and everything is arranged so that the chain is a handful of scalar instructions that never wait for memory:
 //
-// What is brought is not the 514-byte row but its COMPACT form, 192 bytes, made once per call from the table
-// (compact_rows_kernel): the 16 segment heads row[16 t], each paired with w0 in one 32-bit word (a lane gets both with
-// one read and one register), and the 64 entries of the four consecutive segments that hold the most probability mass
-// (the window, segments w0 .. w0 + 3).  The symbol is found with a two-level
-// search, one 16-lane ballot per level: the segment among the heads, then the entry among the segment's 16.  A state
-// that falls into a segment outside the window (the tails of the distribution: rare) reads that segment from the
-// full table in global memory instead.  Three eighths of the bytes per symbol, and a compact table of 3.1 MB that stays
-// in one XCD's L2 where the 8.6 MB of full rows did not.
+//   * What is searched is not the 514-byte row but its COMPACT form, 256 bytes = one 32-bit word per lane, made once per
+//     call from the table (compact_rows_kernel).  Lane l's word holds in its low half entry 16 w0 + l of the row: the
+//     64 entries of the four consecutive segments of 16 that hold the most probability mass (the window, segments
+//     w0 .. w0 + 3); in its high half segment head row[16 l] (lanes 0-15) and w0 (lane 16).  One compare and one
+//     ballot over the low halves give the symbol's position in the window; the two interval ends are read from the
+//     lanes that hold them (v_readlane); coder state, slot, symbol and interval live in scalar registers.  A state that
+//     falls outside the window (the tails of the distribution: rare) finds its segment among the heads and reads the
+//     segment's entries from the full table.  The compact table, 4 MB for the standard model, is served by the L2.
+//   * The row of every symbol is known in advance (prior index of the location, channel), so the words of the next
+//     WAVE_DEPTH symbols' rows are loaded while the current WAVE_DEPTH are decoded: one 4-byte load per lane and symbol.
+//   * The stream's renormalisation words are held 64 at a time in a register (lane l: word base + l), the following 64
+//     are loaded while those are used; the next word is taken out of the register by lane index.  Symbols are stored 64
+//     at a time.
 //
-// Rows travel global -> registers -> LDS, one 16-byte load per lane and symbol for the wave's four streams (48 lanes),
-// INFLIGHT symbols deep.  LDS-DMA is not used for them: a CU performs its LDS-DMA transfers in issue order across ALL
-// of its waves, so the first layer of the analysis transform, which runs beside this kernel in the codec pipeline and
-// streams its weights by LDS-DMA, waited behind this kernel's rows at every step (1.28 -> 1.67 ms for that layer).
-// Full rows through registers would have cost the loader 32 registers in flight; with 48 or fewer per wave two waves
-// of this kernel fit a SIMD beside two 208-register waves of that layer.
+// No LDS and no LDS-DMA: a CU performs its LDS-DMA transfers in issue order across ALL of its waves, so a decoder that
+// brought its rows that way made the first layer of the analysis transform, which runs beside this kernel in the codec
+// pipeline and streams its weights by LDS-DMA, wait behind the rows at every step (1.28 -> 1.67 ms for that layer).
+// The kernel stays under 48 vector registers: two of its waves then fit a SIMD beside two 208-register waves of that layer.
 // ---------------------------------------------------------------------------------------------
-constexpr int RING = 8;                    // LDS row slots per workgroup (power of two, >= AHEAD + 2)
-constexpr int INFLIGHT = 3;                // rows on their way (in registers) behind the newest loaded one
-constexpr int AHEAD = INFLIGHT + 2;        // barriers the loader runs ahead of the decoder: row n is stored before barrier
-                                           // #(n + INFLIGHT) and read behind barrier #(n + AHEAD)
-constexpr int CROW_PIECES = CROW / 8;      // 16-byte pieces of a compact row (CROW entries: 16 x (head, w0), then the 64 window entries)
-constexpr int CROW_WINDOW = 32;            // position of the window
 constexpr int WINDOW_SEGS = 4;
-constexpr int WRING = 256;                 // renormalisation words per stream kept in LDS (two halves of 128)
+constexpr int WAVE_DEPTH = 16;             // symbols whose row words are in registers ahead of the chain (and as many in flight)
+constexpr int WAVE_STREAMS_PER_BLOCK = 4;
 
-// s_waitcnt immediate for "vmcnt <= n" alone (gfx9 encoding: vmcnt bits [3:0] and [15:14], other counters at maximum)
-#define MPC_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
-
-// table [rows][257] -> out [rows][CROW]; one 16-lane group per row.
-__global__ __launch_bounds__(256) void compact_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, uint16_t *__restrict__ out) {
+// table [rows][257] -> out [rows][64] words; one 16-lane group per row.
+__global__ __launch_bounds__(256) void compact_rows_kernel(const uint16_t *__restrict__ table, int64_t rows, uint32_t *__restrict__ out) {
     const int t = threadIdx.x & 15;
     const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (r >= rows) return;                                 // whole groups leave together
     const uint16_t *row = table + r * 257;
-    uint16_t *o = out + r * CROW;
+    uint32_t *o = out + r * (CROW / 2);
     const uint32_t head = row[16 * t];
     // mass of the window that starts at segment t: row[16 (t + 4)] - row[16 t], the row's end counting as 2^16
     const uint32_t upper = (t + WINDOW_SEGS <= 15) ? (uint32_t)row[16 * (t + WINDOW_SEGS)] : 0x10000u;
     uint32_t key = (t <= 16 - WINDOW_SEGS) ? (((upper - head) << 4) | (uint32_t)(15 - t)) : 0u;   // largest mass, then smallest t
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) key = max(key, (uint32_t)__shfl_xor((int)key, off, 16));
-    const int w0 = 15 - (int)(key & 15u);
-    ((uint32_t *)o)[t] = head | ((uint32_t)w0 << 16);
-    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-    u16x4 w;
+    const uint32_t w0 = 15u - (key & 15u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = row[16 * w0 + 4 * t + q];
-    *(u16x4 *)(o + CROW_WINDOW + 4 * t) = w;
+    for (int q = 0; q < WINDOW_SEGS; ++q) {
+        const uint32_t high = q == 0 ? head : (q == 1 && t == 0 ? w0 : 0u);
+        o[16 * q + t] = (uint32_t)row[16 * (w0 + q) + t] | (high << 16);
+    }
 }
 
-// Workgroup = two waves working on the same four streams: wave 1 brings the compact rows into an LDS ring (the
-// loader), wave 0 runs the coder states, one 16-lane group per stream (the decoder); they meet at one raw s_barrier
-// per symbol:
-//   loader, iteration i : load row i into registers; store row i - INFLIGHT to its ring slot, wait for the store; barrier #i
-//   decoder, step n     : barrier #(n + AHEAD); search row n, read the segment heads and w0 of row n + 1
-// Row n + 1 is in LDS before barrier #(n + 1 + INFLIGHT) <= #(n + AHEAD).  The loader overwrites the slot of row
-// r - RING when it stores row r, behind barrier #(r + INFLIGHT - 1), which the decoder passes no earlier than in
-// step r + INFLIGHT - 1 - AHEAD, when the oldest row it can still read is that step's own: > r - RING.  Both waves
-// execute nmax + AHEAD barriers.
-//
-// The decoder's serial chain per symbol is: ballot over the 16 segment heads (in registers, read a step ahead) ->
-// read the segment's 16 entries (window in LDS, or the full table) -> ballot -> (start, end) by lane exchange -> new
-// state.  The next renormalisation word is read from an LDS copy of the stream's words a step ahead as well.
-__global__ __launch_bounds__(128) void decode_streams_ring_kernel(Geometry g, const uint16_t *__restrict__ compact,
+// ALIGNED: M is a multiple of WAVE_DEPTH.  A pass then lies inside one location (a stream starts on a location), its
+// WAVE_DEPTH rows are consecutive in the compact table -- one address and WAVE_DEPTH loads at fixed offsets -- and a
+// stream is a whole number of passes.  Otherwise every symbol's row is addressed on its own and the last pass may be short.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void decode_streams_wave_kernel(Geometry g, const uint32_t *__restrict__ compact,
                                                                    const uint16_t *__restrict__ table,
                                                                    const int32_t *__restrict__ idx,
                                                                    const uint8_t *__restrict__ in, size_t in_stride,
                                                                    const uint64_t *__restrict__ nbytes,
                                                                    int16_t *__restrict__ sym_out,
                                                                    int32_t *__restrict__ status) {
-    static_assert(RING >= AHEAD + 2 && (RING & (RING - 1)) == 0, "ring too small for the loader's lead");
-    __shared__ __attribute__((aligned(16))) uint16_t ring[RING][4][CROW];        // [slot][group][compact row]
-    __shared__ __attribute__((aligned(16))) uint16_t wring[4][WRING];            // renormalisation words per group
-    __shared__ uint32_t info[4][3];                                              // per group: first symbol, end symbol, image
-    __shared__ uint32_t nmax_sh;
-    const int lane = threadIdx.x & 63;
-    const bool loader = (threadIdx.x >> 6) == 1;
-    const int t = lane & (GROUP - 1);
-    const int gw = lane / GROUP;                           // group within the wave
-    const int gshift = lane & ~(GROUP - 1);                // bit offset of this group in a wave ballot
+    const uint32_t lane = threadIdx.x & 63;
+    // (the wave's index through readfirstlane: the compiler then knows that everything derived from it is the same in
+    // all lanes and keeps it, the coder state included, in scalar registers)
+    const int64_t gid = (int64_t)blockIdx.x * WAVE_STREAMS_PER_BLOCK + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t G = (int64_t)g.n_images * g.n_streams;
+    if (gid >= G) return;                                   // whole waves leave together
+    const int img = (int)(gid / g.n_streams);
+    const uint32_t stream = (uint32_t)(gid % g.n_streams);
+    const uint8_t *src = in + (size_t)img * in_stride;
+    const uint64_t nb = nbytes[img];
+    const uint64_t hdr = 16 + 2 * (uint64_t)g.n_streams;   // the host has checked hdr <= in_stride < 2^32
     const uint32_t M = (uint32_t)g.M;
-
-    // ---- stream set-up (decoder wave), handed to the loader through LDS ----
     int err = 0;
-    uint32_t my_len = 0, b = 0, e = 0;
-    int img = 0;
-    const uint16_t *words = nullptr;
-    bool live = false;
-    if (!loader) {
-        const int64_t gid = (int64_t)blockIdx.x * 4 + gw;
-        live = gid < G;                                    // dead groups idle through the loop
-        img = live ? (int)(gid / g.n_streams) : 0;
-        const uint32_t stream = live ? (uint32_t)(gid % g.n_streams) : 0;
-        const uint8_t *src = in + (size_t)img * in_stride;
-        const uint64_t nb = nbytes[img];
-        const uint64_t hdr = 16 + 2 * (uint64_t)g.n_streams;   // the host has checked hdr <= in_stride < 2^32
-        if (nb < hdr || nb > in_stride) err = -20;
-        uint32_t off = (uint32_t)hdr;
-        if (!err) {
-            const uint32_t *h4 = (const uint32_t *)src;
-            if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
-        }
-        if (!err) {
-            const uint16_t *lens = (const uint16_t *)(src + 16);
-            uint32_t acc = 0;
-            for (uint32_t j = t; j < stream; j += GROUP) acc += lens[j];
-            off += 2 * group_sum(acc);
-            my_len = lens[stream];
-            if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
-        }
-        words = (const uint16_t *)(src + off);
-        if (live && !err) {
-            b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
-            e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
-        }
-        if (b < e) {                                       // validate the prior indices of this stream once
-            const int32_t *img_idx = idx + (int64_t)img * g.n_loc;
-            for (uint32_t l = b / M + t; l < (e + M - 1) / M; l += GROUP) {
-                int k = img_idx[l];
-                if (k < 0 || k >= g.K) err = -23;
-            }
-            if (__ballot(err != 0) >> gshift & 0xffffu) err = -23;
-            if (err) e = b;
-        }
-        uint32_t nm = e - b;
-#pragma unroll
-        for (int o = 32; o >= GROUP; o >>= 1) nm = max(nm, (uint32_t)__shfl_xor((int)nm, o, 64));
-        if (t == 0) { info[gw][0] = b; info[gw][1] = e; info[gw][2] = (uint32_t)img; }
-        if (lane == 0) nmax_sh = nm;
+    if (nb < hdr || nb > in_stride) err = -20;
+    uint32_t my_len = 0, off = (uint32_t)hdr;
+    if (!err) {
+        const uint32_t *h4 = (const uint32_t *)src;
+        if (h4[0] != MRS1_MAGIC || h4[1] != (uint32_t)g.n_streams || h4[2] != g.n_symbols || h4[3] != g.sps) err = -21;
     }
-    __syncthreads();
-    const uint32_t nmax = nmax_sh;                         // trip count of the workgroup
-    if (nmax == 0) {
-        if (!loader && err && live && t == 0) atomicMin(&status[img], err);
-        return;
+    if (!err) {
+        const uint16_t *lens = (const uint16_t *)(src + 16);
+        uint32_t acc = 0;
+        for (uint32_t j = lane; j < stream; j += 64) acc += lens[j];
+        acc = group_sum(acc);
+        acc = lane_value(acc, 0) + lane_value(acc, 16) + lane_value(acc, 32) + lane_value(acc, 48);
+        off += 2 * acc;
+        my_len = lens[stream];
+        if (my_len < 2 || (uint64_t)off + 2ull * my_len > nb) err = -22;
     }
-
-    if (loader) {
-        // Lane l < 48 brings piece l % 12 of the compact row of group l / 12; the ring slot [4][CROW] is lane-linear for
-        // that.  A lane's cursor walks the symbols b, b + 1, ... of its group's stream and stays on the last one at the end.
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const bool active = lane < 4 * CROW_PIECES;
-        const int lg = active ? lane / CROW_PIECES : 0, piece = active ? lane - lg * CROW_PIECES : 0;
-        const uint32_t qb = info[lg][0], ce = info[lg][1];
-        const int32_t *cidx = idx + (int64_t)info[lg][2] * g.n_loc;
-        uint32_t ci = qb, cc = qb % M, cloc = qb / M;
-        const uint16_t *crow = compact + 8 * piece;        // (an empty stream reads row 0: unused)
-        if (qb < ce) crow += ((int64_t)cidx[cloc] * M + cc) * CROW;
-        f4 staged[INFLIGHT + 1];
-        f4 *const dst = (f4 *)&ring[0][0][0] + lane;       // + slot * 4 * CROW_PIECES
-        __builtin_amdgcn_s_waitcnt(0);                     // the set-up's LDS reads are done before the ring is written
-        // iteration i, register u = i % (INFLIGHT + 1): load row i, store row i - INFLIGHT (register (u + 1) % (INFLIGHT + 1)), barrier #i
-#define MPC_LOADER_STEP(U)                                                                                              \
-        {                                                                                                               \
-            if (i < nmax && active) {                                                                                   \
-                staged[U] = *(const f4 *)crow;                                                                          \
-                if (ci + 1 < ce) {                                                                                      \
-                    ++ci;                                                                                               \
-                    if (++cc == M) {                                                                                    \
-                        cc = 0;                                                                                         \
-                        ++cloc;                                                                                         \
-                        crow = compact + 8 * piece + (int64_t)cidx[cloc] * M * CROW;   /* indices were validated above */ \
-                    } else {                                                                                            \
-                        crow += CROW;                                                                                   \
-                    }                                                                                                   \
-                }                                                                                                       \
-            }                                                                                                           \
-            if (i >= (uint32_t)INFLIGHT && i - INFLIGHT < nmax && active)                                               \
-                dst[((i - INFLIGHT) & (RING - 1)) * (4 * CROW_PIECES)] = staged[((U) + 1) % (INFLIGHT + 1)];            \
-            __builtin_amdgcn_s_waitcnt((63 & 15) | ((63 >> 4) << 14) | (7 << 4) | (0 << 8));   /* lgkmcnt(0): the row is in LDS */ \
-            __builtin_amdgcn_s_barrier();                  /* #i */                                                     \
-            asm volatile("" ::: "memory");                                                                              \
-            ++i;                                                                                                        \
-        }
-        static_assert(INFLIGHT == 3 && AHEAD >= INFLIGHT + 1, "the loader is unrolled over INFLIGHT + 1 = 4 registers");
-        const uint32_t total = nmax + AHEAD;               // barriers #0 .. #(nmax + AHEAD - 1), as many as the decoder wave executes
-        uint32_t i = 0;
-        while (i + 4 <= total) {
-            MPC_LOADER_STEP(0) MPC_LOADER_STEP(1) MPC_LOADER_STEP(2) MPC_LOADER_STEP(3)
-        }
-        if (i < total) MPC_LOADER_STEP(0)
-        if (i < total) MPC_LOADER_STEP(1)
-        if (i < total) MPC_LOADER_STEP(2)
-#undef MPC_LOADER_STEP
-        return;
-    }
-
-    // ---- decoder wave ----
-    if (err && live && t == 0) atomicMin(&status[img], err);
+    const uint32_t b = (uint32_t)min((uint64_t)stream * g.sps, (uint64_t)g.n_symbols);
+    const uint32_t e = (uint32_t)min((uint64_t)b + g.sps, (uint64_t)g.n_symbols);
     const uint32_t len = e - b;
-    // (addresses that are needed once in 16 symbols, or on the rare tail path, are formed from `img` where they are
-    // used: every register counts, 48 is the budget that lets two of these waves sit beside a transform's)
-    // the stream's renormalisation words go through an LDS ring of two 128-word halves: lane t brings 8 words
-    uint16_t *wr = &wring[gw][0];
-    auto fill_half = [&](uint32_t first) {                 // words [first, first + 128) -> ring half (first / 128) & 1
-        const uint32_t k0 = first + 8 * t;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (len && k0 + 8 <= my_len) {
-            v = *(const uint4 *)(words + k0);
-        } else if (len && k0 < my_len) {
-            uint16_t tmp[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) tmp[q] = (k0 + q < my_len) ? words[k0 + q] : (uint16_t)0;
-            v = make_uint4(tmp[0] | (uint32_t)tmp[1] << 16, tmp[2] | (uint32_t)tmp[3] << 16, tmp[4] | (uint32_t)tmp[5] << 16,
-                           tmp[6] | (uint32_t)tmp[7] << 16);
+    const int32_t *img_idx = idx + (int64_t)img * g.n_loc;
+    if (!err && len) {                                      // validate the prior indices of this stream once
+        bool bad = false;
+        for (uint32_t l = b / M + lane; l < (e + M - 1) / M; l += 64) {
+            const int k = img_idx[l];
+            bad |= k < 0 || k >= g.K;
         }
-        *(uint4 *)(wr + ((first + 8 * t) & (WRING - 1))) = v;
-    };
-    fill_half(0);
-    fill_half(128);
-    uint32_t x = len ? ((uint32_t)words[0] | ((uint32_t)words[1] << 16)) : RANS_L;
-    uint32_t wpos = 2, wbase = 0;                          // next word to consume; ring holds words [wbase, wbase + 256)
-    const uint16_t *rbase = &ring[0][gw][0];               // this group's row in slot 0
+        if (__ballot(bad)) err = -23;
+    }
+    if (err) {
+        if (lane == 0) atomicMin(&status[img], err);
+        return;
+    }
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    my_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_len);
+    const uint16_t *words = (const uint16_t *)(src + off);
+    // The stream's words: wa holds words [wbase, wbase + 64), wb the 64 behind them, lane l word l of each.  The chain reads
+    // only these two; the words behind them are loaded into wc and moved into place at the top of a later pass, so that
+    // nothing the chain reads is the target of a load in flight (the compiler would wait for it at every renormalisation).
+    // (indices clamped, not guarded: a guarded load is waited for where the guard ends; what lies past the end is never used)
+    auto load_words = [&](uint32_t base) -> uint32_t { return (uint32_t)words[min(base + lane, my_len - 1)]; };
+    uint32_t wa = load_words(0), wb = load_words(64), wc = 0;
+    bool wc_loaded = false;
+    uint32_t x = lane_value(wa, 0) | (lane_value(wa, 1) << 16);
+    uint32_t wi = 2, wbase = 0;                             // words taken so far; first word of wa
+    uint32_t wnext = lane_value(wa, 2);                     // (past the end: never used, a renormalisation there is an error)
+    if (len == 0) {
+        if (x != RANS_L || my_len != 2) { if (lane == 0) atomicMin(&status[img], -26); }
+        return;
+    }
+    int16_t *dst = sym_out + (int64_t)img * g.n_symbols + b;
 
-#pragma unroll
-    for (int k = 0; k < AHEAD; ++k) __builtin_amdgcn_s_barrier();      // #0 .. #(AHEAD-1): rows 0 and 1 are in LDS
-    asm volatile("" ::: "memory");
-    uint32_t heads = ((const uint32_t *)rbase)[t];        // segment head t of row 0 (low half) and the row's w0 (high half)
-    uint32_t wnext = wr[wpos & (WRING - 1)];
-    uint32_t xslot = x & 0xffffu;
-    uint32_t mysym = 0;
-    for (uint32_t n = 0; n < nmax; ++n) {
-        __builtin_amdgcn_s_barrier();                      // #(n + AHEAD): rows up to n + 1 are in LDS
-        asm volatile("" ::: "memory");
-        const uint16_t *row = rbase + (n & (RING - 1)) * (4 * CROW);
-        const uint16_t *row_nx = rbase + ((n + 1) & (RING - 1)) * (4 * CROW);
-        const uint32_t heads_nx = ((const uint32_t *)row_nx)[t];      // off the chain
-        if (n < len) {
-            unsigned long long m1 = __ballot((heads & 0xffffu) <= xslot);
-            uint32_t seg_cnt = __popc((uint32_t)(m1 >> gshift) & 0xffffu);
-            uint32_t seg = seg_cnt ? seg_cnt - 1 : 0;      // a row starts at 0, so seg_cnt >= 1 unless the table is corrupt
-            const uint32_t rel = seg - (heads >> 16);
-            const bool inside = rel < (uint32_t)WINDOW_SEGS;
-            uint32_t ent = row[CROW_WINDOW + 16 * (inside ? rel : 0u) + t];
-            if (!inside) {                                  // the state fell into a tail segment: its entries from the full table
-                const uint32_t sidx = b + n;
-                const uint32_t loc = sidx / M, c = sidx - loc * M;
-                const uint16_t *full = table + ((int64_t)idx[(int64_t)img * g.n_loc + loc] * M + c) * 257;
-                ent = full[16 * seg + t];
+    // the cursor that runs WAVE_DEPTH .. 2 WAVE_DEPTH symbols ahead of the chain and stays on the last symbol (pass) at the end
+    uint32_t pf_n = 0, pf_c = 0, pf_loc = b / M;            // (a stream starts on a location: b is a multiple of M)
+    int64_t pf_row = (int64_t)img_idx[pf_loc] * M;
+    auto next_row_word = [&]() -> uint32_t {
+        const uint32_t w = compact[(pf_row + pf_c) * (CROW / 2) + lane];
+        if (pf_n + 1 < len) {
+            ++pf_n;
+            if (++pf_c == M) {
+                pf_c = 0;
+                ++pf_loc;
+                pf_row = (int64_t)img_idx[pf_loc] * M;
             }
-            unsigned long long m2 = __ballot(ent <= xslot);
-            uint32_t in_seg = __popc((uint32_t)(m2 >> gshift) & 0xffffu);
-            uint32_t s = 16 * seg + (in_seg ? in_seg - 1 : 0);
-            // (start, end) = entries s and s + 1: both among the 16 just compared, or the next segment's head, or the row's end
-            const uint32_t start = (uint32_t)__shfl((int)ent, (int)(in_seg ? in_seg - 1 : 0), GROUP);
-            const uint32_t end_in = (uint32_t)__shfl((int)ent, (int)(in_seg & 15u), GROUP);
-            const uint32_t end_hd = (uint32_t)__shfl((int)heads, (int)((seg + 1) & 15u), GROUP) & 0xffffu;
-            const uint32_t end = in_seg < 16u ? end_in : (seg == 15u ? 0x10000u : end_hd);
-            x = (end - start) * (x >> 16) + xslot - start;
-            const bool ren = x < RANS_L;
-            if (ren) x = (x << 16) | wnext;
-            xslot = x & 0xffffu;
-            // ---- off the chain ----
-            if (seg_cnt == 0 || in_seg == 0) err = -24;
-            if (ren) {
-                if (wpos >= my_len) err = -25;
-                ++wpos;
-                if (wpos - wbase == 128 + 2) {             // a half is behind us (two words of slack): refill it
-                    fill_half(wbase + WRING);
-                    wbase += 128;
+        }
+        return w;
+    };
+    auto next_pass = [&](uint32_t (&rows)[WAVE_DEPTH]) {
+        if constexpr (ALIGNED) {
+            const uint32_t *p = compact + (pf_row + pf_c) * (CROW / 2) + lane;
+#pragma unroll
+            for (int u = 0; u < WAVE_DEPTH; ++u) rows[u] = p[u * (CROW / 2)];
+            if (pf_n + WAVE_DEPTH < len) {
+                pf_n += WAVE_DEPTH;
+                pf_c += WAVE_DEPTH;
+                if (pf_c == M) {
+                    pf_c = 0;
+                    ++pf_loc;
+                    pf_row = (int64_t)img_idx[pf_loc] * M;
                 }
             }
-            wnext = wr[wpos & (WRING - 1)];
-            // symbols are written 16 at a time, one per lane
-            if (t == (int)(n & 15)) mysym = s;
-            if ((n & 15) == 15 || n + 1 == len) {
-                uint32_t first = n & ~15u;
-                if (first + t <= n) sym_out[(int64_t)img * g.n_symbols + b + first + t] = decoded_value(g, (int)mysym);
+        } else {
+#pragma unroll
+            for (int u = 0; u < WAVE_DEPTH; ++u) rows[u] = next_row_word();
+        }
+    };
+    uint32_t cur[WAVE_DEPTH], nxt[WAVE_DEPTH];
+    next_pass(cur);
+    uint32_t mysym = 0;
+    // What went wrong, as flags: the chain does not stop inside a pass (every read it makes stays in bounds whatever the
+    // state is), the loop ends behind the pass.  1: slot below a row's first entry (-24); 2: the stream's words ran out (-25).
+    uint32_t bad = 0;
+    for (uint32_t n0 = 0; n0 < len && !bad; n0 += WAVE_DEPTH) {
+        // ---- off the chain: loads for later passes ----
+        if (wc_loaded) {
+            wb = wc;
+            wc_loaded = false;
+        }
+        if (wi - wbase >= 64) {                             // (a pass takes at most WAVE_DEPTH words: wb is not needed before the next pass)
+            wa = wb;
+            wbase += 64;
+            wc = load_words(wbase + 64);
+            wc_loaded = true;
+        }
+        next_pass(nxt);
+#pragma unroll
+        for (int u = 0; u < WAVE_DEPTH; ++u) {              // (no early exit from this loop: it must unroll, cur[] lives in registers)
+            const uint32_t n = n0 + u;
+            if (ALIGNED || n < len) {
+                const uint32_t w = cur[u];
+                // ---- the chain: state -> symbol -> new state, in scalar registers ----
+                const uint32_t slot = x & 0xffffu;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot((w & 0xffffu) <= slot));
+                uint32_t sym, start, end;
+                if (cnt >= 1 && cnt <= 63) {
+                    sym = 16 * (lane_value(w, 16) >> 16) + cnt - 1;
+                    start = lane_value(w, cnt - 1) & 0xffffu;
+                    end = lane_value(w, cnt) & 0xffffu;
+                } else {
+                    // outside the window: the segment among the heads, its entries (and the head behind them) from the full table
+                    const uint32_t seg_cnt = __popc((uint32_t)__ballot((w >> 16) <= slot) & 0xffffu);
+                    const uint32_t seg = seg_cnt ? seg_cnt - 1 : 0;
+                    const uint32_t sidx = b + n, loc = sidx / M, c = sidx - loc * M;
+                    const uint16_t *full = table + ((int64_t)img_idx[loc] * M + c) * 257;
+                    const uint32_t at = 16 * seg + lane;
+                    const uint32_t ent = (lane <= 16 && at < 256) ? (uint32_t)full[at] : 0x10000u;
+                    const uint32_t in_seg = __popc((uint32_t)__ballot(ent <= slot) & 0xffffu);
+                    if (seg_cnt == 0 || in_seg == 0) bad |= 1;         // a row starts at 0: the table is corrupt
+                    sym = 16 * seg + in_seg - 1;
+                    start = lane_value(ent, (in_seg - 1) & 63);
+                    end = lane_value(ent, in_seg);
+                }
+                x = (end - start) * (x >> 16) + slot - start;
+                if (x < RANS_L) {
+                    if (wi >= my_len) bad |= 2;
+                    x = (x << 16) | wnext;
+                    ++wi;
+                    const uint32_t pos = wi - wbase;
+                    wnext = pos < 64 ? lane_value(wa, pos) : lane_value(wb, (pos - 64) & 63);
+                }
+                if (lane == (n & 63)) mysym = sym;
             }
         }
-        heads = heads_nx;
+        // ---- off the chain: symbols are stored 64 at a time, one per lane ----
+        if (!bad && ((n0 & 63) == 64 - WAVE_DEPTH || n0 + WAVE_DEPTH >= len)) {
+            const uint32_t base = n0 & ~63u;
+            if (base + lane < min(n0 + WAVE_DEPTH, len)) dst[base + lane] = decoded_value(g, (int)mysym);
+        }
+#pragma unroll
+        for (int u = 0; u < WAVE_DEPTH; ++u) cur[u] = nxt[u];
     }
-    if (len && !err && (x != RANS_L || wpos != my_len)) err = -26;
-    if (err && live && t == 0) atomicMin(&status[img], err);
+    err = (bad & 1) ? -24 : (bad & 2) ? -25 : 0;
+    if (!err && (x != RANS_L || wi != my_len)) err = -26;
+    if (err && lane == 0) atomicMin(&status[img], err);
 }
 
 int check_geometry(mpc_ctx *ctx, Geometry &g, int K, int M, int L, int n_images, int64_t n_loc, int n_streams,
@@ -969,13 +915,14 @@ static int rans_decode_launch(mpc_ctx *ctx, const Geometry &g, const int16_t *ta
     const int64_t G = (int64_t)g.n_images * g.n_streams;
     MPC_HIP(ctx, hipMemsetAsync(status_dev, 0, sizeof(int32_t) * g.n_images, ctx->stream));
     if (g.L == 257) {
-        // compact form of the table for the loader wave (rebuilt per call: the caller may have changed the table)
+        // compact form of the table (rebuilt per call: the caller may have changed the table)
         const int64_t rows = (int64_t)g.K * g.M;
         compact_rows_kernel<<<dim3((unsigned)mpc_cdiv(rows, 16)), dim3(256), 0, ctx->stream>>>((const uint16_t *)table, rows,
-                                                                                            (uint16_t *)compact_rows);
+                                                                                            (uint32_t *)compact_rows);
         MPC_CHECK_LAUNCH(ctx, "rans compact_rows");
-        decode_streams_ring_kernel<<<dim3((unsigned)mpc_cdiv(G, 4)), dim3(128), 0, ctx->stream>>>(
-            g, (const uint16_t *)compact_rows, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
+        auto kern = g.M % WAVE_DEPTH == 0 ? decode_streams_wave_kernel<true> : decode_streams_wave_kernel<false>;
+        kern<<<dim3((unsigned)mpc_cdiv(G, WAVE_STREAMS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
+            g, (const uint32_t *)compact_rows, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);
     } else {
         decode_streams_kernel<<<dim3((unsigned)mpc_cdiv(G, GROUPS_PER_BLOCK)), dim3(256), 0, ctx->stream>>>(
             g, (const uint16_t *)table, idx, in, in_stride, nbytes_dev, sym_out, status_dev);

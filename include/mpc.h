@@ -195,9 +195,9 @@ int mpc_rans_encode_auto(mpc_ctx *ctx, const int16_t *table, int K, int M, int L
  * into sym_out + i*n_loc*M.  n_streams / locs_per_stream are the values the containers were written
  * with (fields 1 and 3 of the header; every image of the batch must share them).  status_dev[i]
  * (device int32) is 0 or a negative detail code of MPC_EDATA.  Tables with L = 257 (256-symbol rows, the standard
- * model) take the fast path: rows brought into LDS by a loader wave, searched by a decoder wave; it works on a
- * compact copy of the table made by this call in the context's scratch (K*M*192 bytes: per row the 16 segment heads
- * and the 64 entries of the four heaviest consecutive segments; other segments are read from `table` itself). */
+ * model) take the fast path: one wave per stream, the coder state in scalar registers; it works on a compact copy
+ * of the table made by this call in the context's scratch (K*M*256 bytes: per row the 16 segment heads and the 64
+ * entries of the four heaviest consecutive segments; other segments are read from `table` itself). */
 int mpc_rans_decode(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                     const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
                     int64_t n_loc, int n_streams, int locs_per_stream, int16_t *sym_out,
@@ -214,7 +214,7 @@ int mpc_rans_decode_latent_f16(mpc_ctx *ctx, const int16_t *table, int K, int M,
 /* Same as mpc_rans_decode, for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): it calls no allocating routine.  It has no counterpart in the
  * reference.  The compact table copy lives in a static device array of the library instead of context scratch:
- * L must be 257 and K*M at most 16384 rows (3 MiB per GPU, held until the process ends), otherwise MPC_EINVAL.
+ * L must be 257 and K*M at most 16384 rows (4 MiB per GPU, held until the process ends), otherwise MPC_EINVAL.
  * All calls on one GPU share that array: calls that overlap in time on one GPU (two streams, two contexts) race. */
 int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, int L, const int32_t *idx,
                             const uint8_t *in, size_t in_stride, const uint64_t *nbytes_dev, int n_images,
