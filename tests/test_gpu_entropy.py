@@ -339,3 +339,43 @@ def test_fast_decoder_outside_its_row_window(dev, ops):
     dec, st = ops.rans_decode(td, idxd, out, nbytes, n_img, n_streams, lps)
     assert st.cpu().tolist() == [0] * n_img
     assert torch.equal(dec.cpu(), sym)
+
+
+@pytest.mark.parametrize("M2,n_loc,n_streams", [(10, 37, 1), (24, 64, 3), (48, 41, 2), (16, 200, 1), (256, 9, 2)])
+def test_fast_decoder_channel_counts_and_long_streams(dev, ops, M2, n_loc, n_streams):
+    """The 256-symbol decoder loads the rows of 16 symbols per pass: with a channel count that is a multiple of 16 a pass
+    lies inside one location (one address, fixed offsets), otherwise every symbol's row is addressed on its own and the
+    last pass of a stream is short.  Streams of up to 3 200 symbols: several hundred renormalisation words, which go
+    through the decoder's three word registers many times.  Narrow and wide rows mixed, symbols drawn from the rows'
+    own distributions.  Bytes against the scalar specification, symbols from both decoders."""
+    K2, n_img = 5, 2
+    g = torch.Generator().manual_seed(1000 + M2)
+    t = torch.linspace(-127.5, 128.5, 257)
+    scale = torch.exp(torch.rand(K2, M2, 1, generator=g) * 5.0 - 2.0)    # 0.14 .. 20
+    centre = torch.round((torch.rand(K2, M2, 1, generator=g) - 0.5) * 60.0)
+    tf = 0.5 - 0.5 * torch.sign(t - centre) * torch.expm1(-(t - centre).abs() / scale)
+    table = O.renorm_cast_cdf(tf.contiguous(), 16, 0)
+    idx = torch.randint(0, K2, (n_img, n_loc), generator=g, dtype=torch.int32)
+    u = torch.rand(n_img, n_loc, M2, generator=g) - 0.5
+    rows_scale, rows_centre = scale[idx.long(), :, 0], centre[idx.long(), :, 0]
+    y = rows_centre + torch.round(-rows_scale * torch.sign(u) * torch.log1p(-2 * u.abs()))
+    sym = (y + 127).clamp(0, 255).to(torch.int16).reshape(n_img, -1)
+    lps = -(-n_loc // n_streams)
+    n_streams = -(-n_loc // lps)
+    td, idxd = table.to(dev), idx.reshape(-1).to(dev)
+    out, nbytes, status = ops.rans_encode(td, idxd, sym.reshape(-1).to(dev), n_img, n_streams, lps)
+    assert status.cpu().tolist() == [0] * n_img
+    nb = nbytes.cpu().tolist()
+    tnp = table.numpy()
+    for i in range(n_img):
+        got = out[i, :nb[i]].cpu().numpy().tobytes()
+        assert got == coders.mrs1_encode(tnp, idx[i].numpy(), sym[i].numpy(), n_streams, lps * M2)
+        assert np.array_equal(coders.mrs1_decode(tnp, idx[i].numpy(), got), sym[i].numpy())
+    dec, st = ops.rans_decode(td, idxd, out, nbytes, n_img, n_streams, lps)
+    assert st.cpu().tolist() == [0] * n_img
+    assert torch.equal(dec.cpu(), sym)
+    # one word less than the stream needs: reported, whatever the state does afterwards
+    short = nbytes.clone()
+    short[0] -= 2
+    _, st = ops.rans_decode(td, idxd, out, short, n_img, n_streams, lps)
+    assert st.cpu()[0].item() < 0 and st.cpu()[1].item() == 0
