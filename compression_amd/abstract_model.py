@@ -171,8 +171,8 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
 
         The main stream is coded under per-element Laplace(0, sigma) rows that are evaluated where they are needed
         (mpc_rans_encode_laplace: two row entries per symbol) -- the reference materialises all of them
-        (abstract_model.py:409-416, 514 bytes per symbol); here the only per-symbol scratch is the coder's 4-byte
-        (start, frequency) word."""
+        (abstract_model.py:409-416, 514 bytes per symbol); here the only per-symbol scratch is the coder's 8-byte
+        (start, frequency, reciprocal) entry."""
         self._require_eval()
         x = input_image.contiguous()
         B, _, H, W = x.shape

@@ -5,10 +5,12 @@
 //
 // Encoder = three launches.
 //   1. symbol_params: one thread per symbol, fully parallel: gathers (start, freq) of the symbol from
-//      the int16 table (2 B symbol + two 2 B table entries read, 4 B written) and stores them
-//      transposed, params[r][stream], so that step 2 reads coalesced.
+//      the int16 table (2 B symbol + two 2 B table entries read) and stores them with floor(2^32 / freq)
+//      (8 B written), transposed, params[r][stream], so that step 2 reads coalesced.
 //   2. encode_streams: one LANE per stream (rANS is sequential within a stream).  Walks the stream's
-//      symbols backwards, emits 16-bit words backwards into the stream's scratch slot.
+//      symbols backwards, emits 16-bit words backwards into the stream's scratch slot.  The state's
+//      division by freq is a multiplication by the stored reciprocal and one correction: the division
+//      sequence was most of a step's serial chain.
 //   3. compact: per image, exclusive scan of the stream lengths, header, and a copy of every stream's
 //      words to its final offset.
 // Decoder = one launch.  One 16-LANE GROUP per stream: lane t holds entries 16t..16t+15 of the
@@ -94,10 +96,18 @@ __global__ __launch_bounds__(1024) void choose_geometry_kernel(const float *__re
     }
 }
 
+// floor(2^32 / freq) for 1 <= freq <= 2^16, saturated at 2^32 - 1 (freq = 1).  With it q = floor(x / freq) for any
+// 32-bit x is mulhi(x, r) or one more: 2^32 = freq r + t with 0 <= t < freq, so x r / 2^32 lies in (x / freq - 1, x / freq].
+// (The double quotient is exact enough to truncate: a quotient that is not an integer lies at least 1 / freq >= 2^-16
+// below the next one, rounding moves it by at most 2^-21.)
+__device__ __forceinline__ uint32_t reciprocal32(uint32_t freq) {
+    return freq <= 1u ? 0xffffffffu : (uint32_t)(4294967296.0 / (double)freq);
+}
+
 __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const uint16_t *__restrict__ table,
                                                              const int32_t *__restrict__ idx,
                                                              const int16_t *__restrict__ sym,
-                                                             uint32_t *__restrict__ params,
+                                                             uint2 *__restrict__ params,
                                                              int32_t *__restrict__ status, const int32_t *__restrict__ ov) {
     g = resolve(g, ov);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const ui
     if (bad) { start = 0; atomicMin(&status[img], -10); }
     uint32_t stream = local / g.sps, r = local % g.sps;
     int64_t G = (int64_t)g.n_images * g.n_streams;
-    params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = start | (freq << 16);
+    params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = make_uint2(start | (freq << 16), reciprocal32(freq));
 }
 
 // symbol_params for per-element Laplace(0, sigma) rows (the hyperprior's main stream, abstract_model.py:402-423): the
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256) void symbol_params_kernel(Geometry g, const ui
 // [n_images][n_loc][M].
 __global__ __launch_bounds__(256) void symbol_params_laplace_kernel(Geometry g, const float *__restrict__ sigma, float first,
                                                                      float factor, const int16_t *__restrict__ sym,
-                                                                     uint32_t *__restrict__ params,
+                                                                     uint2 *__restrict__ params,
                                                                      int32_t *__restrict__ status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = (int64_t)g.n_images * g.n_symbols;
@@ -146,10 +156,10 @@ __global__ __launch_bounds__(256) void symbol_params_laplace_kernel(Geometry g, 
     if (bad) { start = 0; atomicMin(&status[img], -10); }
     uint32_t stream = local / g.sps, r = local % g.sps;
     int64_t G = (int64_t)g.n_images * g.n_streams;
-    params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = start | (freq << 16);
+    params[(int64_t)r * G + (int64_t)img * g.n_streams + stream] = make_uint2(start | (freq << 16), reciprocal32(freq));
 }
 
-__global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const uint32_t *__restrict__ params,
+__global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const uint2 *__restrict__ params,
                                                              uint16_t *__restrict__ scratch,
                                                              uint32_t *__restrict__ lens, const int32_t *__restrict__ ov) {
     g = resolve(g, ov);
@@ -164,18 +174,19 @@ __global__ __launch_bounds__(64) void encode_streams_kernel(Geometry g, const ui
     uint16_t *buf = scratch + gid * g.cap_words;
     uint32_t pos = g.cap_words;
     uint32_t x = RANS_L;
-    const uint32_t *p = params + gid;
-    auto step = [&](uint32_t sf) {
-        uint32_t start = sf & 0xffffu, freq = sf >> 16;
+    const uint2 *p = params + gid;
+    auto step = [&](uint2 sf) {
+        uint32_t start = sf.x & 0xffffu, freq = sf.x >> 16;
         if (x >= (freq << 16)) { buf[--pos] = (uint16_t)(x & 0xffffu); x >>= 16; }
-        uint32_t q = x / freq;
-        x = (q << 16) + (x - q * freq) + start;
+        uint32_t q = __umulhi(x, sf.y), rem = x - q * freq;  // q = floor(x / freq) or one less (reciprocal32)
+        if (rem >= freq) { ++q; rem -= freq; }
+        x = (q << 16) + rem + start;
     };
     // symbols are consumed backwards; the (start,freq) words of the next 8 are loaded while the current 8
     // are coded (the addresses do not depend on the coder state)
     constexpr int U = 8;
     uint32_t r = n;
-    uint32_t cur[U], nxt[U];
+    uint2 cur[U], nxt[U];
     if (r >= U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = p[(int64_t)(r - 1 - u) * G];
@@ -782,7 +793,8 @@ int check_geometry(mpc_ctx *ctx, Geometry &g, int K, int M, int L, int n_images,
 }
 
 struct Workspace {
-    uint32_t *params, *lens, *offs;
+    uint2 *params;
+    uint32_t *lens, *offs;
     uint16_t *scratch;
     size_t bytes;
 };
@@ -795,7 +807,7 @@ Workspace carve(void *base, int n_images, int64_t n_loc, int M, int n_streams, i
     size_t sps = (size_t)locs_per_stream * M;
     size_t off = 0;
     uint8_t *p = (uint8_t *)base;
-    w.params = (uint32_t *)(p + off); off += align256(sps * G * 4);
+    w.params = (uint2 *)(p + off); off += align256(sps * G * sizeof(uint2));
     w.scratch = (uint16_t *)(p + off); off += align256((sps + 2) * G * 2);
     w.lens = (uint32_t *)(p + off); off += align256(G * 4);
     w.offs = (uint32_t *)(p + off); off += align256(G * 4);
@@ -844,7 +856,7 @@ static Workspace carve_max(void *base, int n_images, int64_t n_loc, int M, int m
     const size_t sym_slots = (size_t)n_images * ((size_t)n_loc + max_streams) * M;     // >= G' * sps for every geometry
     size_t off = 0;
     uint8_t *p = (uint8_t *)base;
-    w.params = (uint32_t *)(p + off); off += align256(sym_slots * 4);
+    w.params = (uint2 *)(p + off); off += align256(sym_slots * sizeof(uint2));
     w.scratch = (uint16_t *)(p + off); off += align256((sym_slots + 2 * G) * 2);
     w.lens = (uint32_t *)(p + off); off += align256(G * 4);
     w.offs = (uint32_t *)(p + off); off += align256(G * 4);

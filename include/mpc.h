@@ -225,8 +225,8 @@ int mpc_rans_decode_noalloc(mpc_ctx *ctx, const int16_t *table, int K, int M, in
  * int16 CDF row of Laplace(0, clamp(sigma[i], 1e-10, 1e10)) at the targets first_target + s, s < L, "add arange, then
  * round" order -- the rows mpc_laplace_cdf_rows would write (abstract_model.py:402-416), handed to torchac.encode_cdf
  * at abstract_model.py:423.  sigma and sym are [n_images][n_loc][M] (NHWC); the encoder evaluates the two row entries
- * of every symbol, the decoder the 32 entries its search looks at; the only per-symbol scratch is the encoder's 4-byte
- * (start, frequency) word in `workspace` (mpc_rans_workspace_bytes).  L at most 257.  Containers, geometry arguments
+ * of every symbol, the decoder the 32 entries its search looks at; the only per-symbol scratch is the encoder's 8-byte
+ * (start, frequency, reciprocal) entry in `workspace` (mpc_rans_workspace_bytes).  L at most 257.  Containers, geometry arguments
  * and status codes as in mpc_rans_encode / mpc_rans_decode. */
 int mpc_rans_encode_laplace(mpc_ctx *ctx, const float *sigma, const int16_t *sym, float first_target, int L,
                             int precision, int n_images, int64_t n_loc, int M, int n_streams, int locs_per_stream,

@@ -290,7 +290,7 @@ def test_hyperprior_batch_round_trip_without_materialised_rows(dev):
     streams = m.encode_batch(x)
     recon = m.decode_batch(streams)
     # the coder's own device memory, measured round the two coder calls with sigma and the symbols in hand: the
-    # encoder's 4-byte (start, frequency) word and 2-byte output word per symbol, the containers, the decoded symbols
+    # encoder's 8-byte (start, frequency, reciprocal) entry and 2-byte output word per symbol, the containers, the decoded symbols
     from compression_amd import ops
     y, yhat = m.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
     _, zhat = m.priorEncoder.forward_nhwc(y, round_out=True)
