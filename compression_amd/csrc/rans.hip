@@ -13,11 +13,12 @@
 //      sequence was most of a step's serial chain.
 //   3. compact: per image, exclusive scan of the stream lengths, header, and a copy of every stream's
 //      words to its final offset.
-// Decoder = one launch.  One 16-LANE GROUP per stream: lane t holds entries 16t..16t+15 of the
-// symbol's 256-entry CDF row (32 B per lane, 512 B coalesced per group), counts entries <= slot and
-// the group sums the counts -> symbol, with the next symbol's row already in flight.  The row
-// address depends only on (idx, channel), never on decoded data, which is what makes the prefetch
-// possible.
+// Decoders.  Rows of any length (decode_streams_kernel): one 16-LANE GROUP per stream, lane t holds entries
+// 16t..16t+15 of the symbol's CDF row, counts entries <= slot and the group sums the counts -> symbol.  The
+// standard 256-symbol rows (decode_streams_wave_kernel) and the per-element Laplace rows of the hyperprior
+// models (decode_streams_laplace_kernel): one WAVE per stream with the coder state in scalar registers; the row
+// address (or the row's sigma) depends only on (idx, channel), never on decoded data, so whatever the search looks
+// at is brought or evaluated ahead of the serial chain.
 #include "mpc_internal.h"
 
 // Scratch of the allocation-free decode entry point: the compact copy of the CDF table (256 bytes per row, see the fast
