@@ -180,25 +180,35 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
         sym_y, clamp_y = ops.latent_to_symbols(yhat, self.min_feat_gaussian, self.q_intv, self._main_L() - 1)
         sym_z, clamp_z = ops.latent_to_symbols(zhat, self.min_feat, self.q_intv, self._n_targets() - 1)
-        if int(clamp_y.item()) or int(clamp_z.item()):
-            raise ValueError("encode: a latent falls outside the CDF tables' range "
-                             f"[{self.min_feat_gaussian},{self.max_feat_gaussian}] / [{self.min_feat},{self.max_feat}]")
         _, h, w, M = yhat.shape
         N = self.out_channel_N
+        coded = entropy_coding and not (H % 64 or W % 64)
+        if coded:
+            self.update_entropy_table()                 # small (N x L); keeps the z table in step with the parameters
+            sigma = self.priorDecoder.forward_nhwc(zhat)
+            bits = ops.laplace_bits_total(yhat, sigma)
+        else:
+            bits = torch.zeros(1, dtype=torch.float64, device=x.device)
+        # one readback for the two clamped counts and the bit estimate the stream count is chosen from
+        n_clamp_y, n_clamp_z, est_bits = torch.cat([clamp_y.view(-1)[:1].double(), clamp_z.view(-1)[:1].double(), bits.view(-1)]).cpu().tolist()
+        if n_clamp_y or n_clamp_z:
+            raise ValueError("encode: a latent falls outside the CDF tables' range "
+                             f"[{self.min_feat_gaussian},{self.max_feat_gaussian}] / [{self.min_feat},{self.max_feat}]")
         if not entropy_coding:
             return sym_y.view(B, h, w, M).permute(0, 3, 1, 2).reshape(B, -1), sym_z.reshape(B, -1)
-        if H % 64 or W % 64:
+        if not coded:
             raise ValueError("entropy-coded encode needs H and W to be multiples of 64")
-        self.update_entropy_table()                     # small (N x L); keeps the z table in step with the parameters
-        sigma = self.priorDecoder.forward_nhwc(zhat)
-        est = float(ops.laplace_bits_total(yhat, sigma).item()) / 8 / B
-        mains = ops.rans_encode_laplace_to_bytes(sigma, sym_y, B, M, self.min_feat_gaussian - 0.5, self._main_L(),
-                                                 self.precision, est)
+        est = est_bits / 8 / B
+        n_loc = h * w
+        main = ops.rans_encode_laplace(sigma, sym_y, B, M, self.min_feat_gaussian - 0.5, self._main_L(), self.precision,
+                                       *ops.choose_streams(n_loc, M, est))
         n_zloc = sym_z.numel() // (B * N)
         zidx = torch.zeros(B * n_zloc, dtype=torch.int32, device=x.device)
         # the z string is a hundredth of the image: its streams are budgeted against the image's bytes, not its own
         # (a handful of streams would make its two coders the longest serial chains of the whole codec)
-        zstrs = ops.rans_encode_to_bytes(self._z_table(), zidx, sym_z, B, est + float(n_zloc * N), budget=ops.MRS1_STREAM_BUDGET / 2)
+        side = ops.rans_encode(self._z_table(), zidx, sym_z.reshape(-1), B,
+                               *ops.choose_streams(n_zloc, N, est + float(n_zloc * N), ops.MRS1_STREAM_BUDGET / 2))
+        mains, zstrs = ops.containers_to_bytes([main, side])   # both coders enqueued, then sizes and payloads read back together
         return [[mains[i], zstrs[i], H, W] for i in range(B)]
 
     def encode(self, input_image, entropy_coding=True):
@@ -227,13 +237,22 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         (h, w), (zh, zw) = self._latent_hw(H, W)
         N, M = self.out_channel_N, self.out_channel_M
         zidx = torch.zeros(B * zh * zw, dtype=torch.int32, device=dev)
-        sym_z = ops.rans_decode_from_bytes(self._z_table(), zidx, [b[1] for b in bitstreams])
+        mains, zstrs = [b[0] for b in bitstreams], [b[1] for b in bitstreams]
+        z_geometry = ops.parse_mrs1_headers(zstrs, zh * zw, N)
+        y_geometry = ops.parse_mrs1_headers(mains, h * w, M)
+        (zdata, znb), (ydata, ynb) = ops._upload_containers(zstrs, dev), ops._upload_containers(mains, dev)
+        sym_z, zstatus = ops.rans_decode(self._z_table(), zidx, zdata, znb, B, *z_geometry)
         zhat = ops.symbols_to_latent(sym_z.view(B, zh, zw, N), self.min_feat, self.q_intv)
         sigma = self.priorDecoder.forward_nhwc(zhat)
         if tuple(sigma.shape) != (B, h, w, M):
             raise ValueError("decode: the z string does not match the image size")
-        sym_y = ops.rans_decode_laplace_from_bytes(sigma, [b[0] for b in bitstreams], M, self.min_feat_gaussian - 0.5,
-                                                   self._main_L(), self.precision)
+        # (a damaged z string gives some sigma or other; both decoders stay inside their buffers whatever they read,
+        # so the two statuses are read back together, once, before the result is used)
+        sym_y, ystatus = ops.rans_decode_laplace(sigma, ydata, ynb, B, M, self.min_feat_gaussian - 0.5, self._main_L(),
+                                                 self.precision, *y_geometry)
+        status = torch.cat([zstatus, ystatus]).cpu().tolist()
+        if min(status) < 0:
+            raise _lib.MpcError(f"corrupt MRS1 stream: decoder status z {status[:B]}, main {status[B:]}")
         yhat = ops.symbols_to_latent(sym_y.view(B, h, w, M), self.min_feat_gaussian, self.q_intv)
         return self.Decoder.forward_nhwc(yhat)
 

@@ -465,6 +465,29 @@ def avg_pool2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def containers_to_bytes(encoded: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]) -> List[List[bytes]]:
+    """[(out uint8 [n_images, stride], nbytes int64 [n_images], status int32 [n_images]), ...] of encoder calls that have
+    been enqueued -> per call the list of its images' MRS1 containers.  Two readbacks whatever the number of calls:
+    all sizes and statuses, then all payloads."""
+    counts = [e[1].numel() for e in encoded]
+    meta = torch.cat([t for out, nbytes, status in encoded for t in (nbytes, status.to(torch.int64))]).cpu().tolist()
+    sizes, at = [], 0
+    for n in counts:
+        nb, st = meta[at:at + n], meta[at + n:at + 2 * n]
+        at += 2 * n
+        if min(st) < 0:
+            raise MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
+        sizes.append(nb)
+    used = [max(nb) for nb in sizes]
+    host = torch.cat([e[0][:, :u].reshape(-1) for e, u in zip(encoded, used)]).cpu().numpy()
+    res, at = [], 0
+    for n, nb, u in zip(counts, sizes, used):
+        rows = host[at:at + n * u].reshape(n, u)
+        at += n * u
+        res.append([rows[i, :nb[i]].tobytes() for i in range(n)])
+    return res
+
+
 def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tensor, n_images: int,
                          est_bytes_per_image: float, budget: float = 0.004) -> List[bytes]:
     """Codes n_images equally shaped images and returns their MRS1 containers as byte strings.  The stream count is
@@ -472,13 +495,7 @@ def rans_encode_to_bytes(table: torch.Tensor, idx: torch.Tensor, sym: torch.Tens
     K, M, L = table.shape
     n_loc = idx.numel() // n_images
     n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image, budget)
-    out, nbytes, status = rans_encode(table, idx.reshape(-1), sym.reshape(-1), n_images, n_streams, lps)
-    meta = torch.cat([nbytes, status.to(torch.int64)]).cpu().tolist()
-    nb, st = meta[:n_images], meta[n_images:]
-    if min(st) < 0:
-        raise MpcError(f"rANS encoder reported {st} (symbol outside the table or zero frequency)")
-    host = out[:, :max(nb)].cpu().numpy()
-    return [host[i, :nb[i]].tobytes() for i in range(n_images)]
+    return containers_to_bytes([rans_encode(table, idx.reshape(-1), sym.reshape(-1), n_images, n_streams, lps)])[0]
 
 
 def parse_mrs1_headers(streams: Sequence[bytes], n_loc: int, M: int) -> Tuple[int, int]:
@@ -590,13 +607,7 @@ def rans_encode_laplace_to_bytes(sigma: torch.Tensor, sym: torch.Tensor, n_image
                                  precision: int, est_bytes_per_image: float) -> List[bytes]:
     n_loc = sym.numel() // (n_images * M)
     n_streams, lps = choose_streams(n_loc, M, est_bytes_per_image)
-    out, nbytes, status = rans_encode_laplace(sigma, sym, n_images, M, first_target, L, precision, n_streams, lps)
-    meta = torch.cat([nbytes, status.to(torch.int64)]).cpu().tolist()
-    nb, st = meta[:n_images], meta[n_images:]
-    if min(st) < 0:
-        raise MpcError(f"rANS encoder reported {st} (symbol outside the row or zero frequency)")
-    host = out[:, :max(nb)].cpu().numpy()
-    return [host[i, :nb[i]].tobytes() for i in range(n_images)]
+    return containers_to_bytes([rans_encode_laplace(sigma, sym, n_images, M, first_target, L, precision, n_streams, lps)])[0]
 
 
 def rans_decode_laplace_from_bytes(sigma: torch.Tensor, streams: List[bytes], M: int, first_target: float, L: int,
