@@ -66,7 +66,7 @@ CONFIGS = {
     5: dict(arch="ManyPriors_DC", batch=8, height=1024, width=1024, mode="codec", data="noisy",
             what="JDC full codec on 8 noisy 1024x1024 images"),
     6: dict(arch="TestolinaHP", batch=24, height=512, width=768, mode="hp_codec", data="smooth",
-            what="hyperprior full codec (encode_batch -> bytes -> decode_batch, main stream under per-element Laplace rows) "
+            what="hyperprior full codec (encode -> bytes -> decode, main stream under per-element Laplace rows) "
                  "on 24 x 768x512 images"),
 }
 # sources whose change invalidates the committed counter passes of the dominant kernel
@@ -473,7 +473,7 @@ def run_rank(args):
 
     def after_synthesis(job, strings, tag):
         xhat, sse = job["recon"], job["sse"]                # clamp and squared error come from the last layer's epilogue
-        nbytes = float(sum(len(s) for s in strings))
+        nbytes = float(sum(len(s) if isinstance(s, bytes) else len(s[0]) + len(s[1]) for s in strings))   # (hyperprior: [main, z, H, W])
         key = torch.cuda.current_stream().cuda_stream
         a = accs.get(key)
         if a is None:
@@ -486,7 +486,7 @@ def run_rank(args):
         from compression_amd import manynets_compressor
         manynets_compressor.SYNTHESIS_MAY_START_BEHIND_LAYER = int(os.environ["MPC_BENCH_SYNTHESIS_BEHIND_LAYER"])
     pipe = None
-    if args.mode == "codec" and not args.serial:
+    if args.mode in ("codec", "hp_codec") and not args.serial:
         from compression_amd.pipeline import CodecPipeline
         pipe = CodecPipeline(model, dev, after_synthesis=after_synthesis,
                              early_first_layer=os.environ.get("MPC_BENCH_EARLY_FIRST_LAYER", "0") == "1",
@@ -537,7 +537,7 @@ def run_rank(args):
         return old if new is None else new
 
     if args.mode == "hp_codec":
-        step = serial_step = hyperprior_codec_step
+        step, serial_step = (hyperprior_codec_step if args.serial else pipelined_codec_step), hyperprior_codec_step
     elif args.mode == "forward":
         step, serial_step = (forward_step if args.serial else pipelined_forward_step), forward_step
     else:

@@ -113,6 +113,11 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         if authority not in ("device", "host"):
             raise ValueError(f"table authority must be 'device' or 'host', got {authority!r}")
         L = self._n_targets()
+        # Built again only when the prior's parameters (or what the table is made with) have changed: the codec calls
+        # this before every batch, and batches that are in flight on different streams share the table.
+        made_from = (authority, L, self.min_feat, self.max_feat, self.precision, tuple((p.data_ptr(), p._version) for p in self.bitEstimator_z.parameters()))
+        if getattr(self, "_z_table_made_from", None) == made_from:
+            return True
         if authority == "host":
             dev = next(self.bitEstimator_z.parameters()).device
             tf = self.bitEstimator_z.table_host(self.min_feat - 0.5, self.max_feat + 0.5, L).to(dev)
@@ -122,6 +127,9 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
             int((-self.min_feat_gaussian + self.max_feat_gaussian) / self.q_intv + 2)
         self.z_entropy_table_float = self.entropy_table_float = tf
         self.z_entropy_table = _renorm_cast_cdf_(tf, self.precision)
+        if tf.is_cuda:
+            torch.cuda.current_stream(tf.device).synchronize()                  # complete before any other stream reads it
+        object.__setattr__(self, "_z_table_made_from", made_from)
         return True
 
     def eval(self):
@@ -138,6 +146,25 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
             {"params": self.priorDecoder.parameters(), "name": "prior_decoder"},
             {"params": self.bitEstimator_z.parameters(), "lr": lr * 10, "name": "bit_estimator"},
         ]
+
+    def _staging(self, nbytes, purpose="bytes"):
+        """Page-locked host buffer of at least nbytes (uint8), reused between calls.  One buffer per purpose and per HIP
+        stream: calls that are in flight on different streams (CodecPipeline) never share one."""
+        bufs = self.__dict__.setdefault("_stage_bufs", {})
+        key = (purpose, torch.cuda.current_stream().cuda_stream)
+        buf = bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        return buf
+
+    def _meta_host(self, n, purpose="meta"):
+        """Page-locked int32 host buffer for the one small readback of a call (per purpose and stream, as above)."""
+        bufs = self.__dict__.setdefault("_meta_bufs", {})
+        key = (purpose, torch.cuda.current_stream().cuda_stream)
+        buf = bufs.get(key)
+        if buf is None or buf.numel() < n:
+            buf = bufs[key] = torch.empty(max(n, 256), dtype=torch.int32, pin_memory=True)
+        return buf[:n]
 
     # ---- entropy-coded encode / decode (abstract_model.py:370-500) ----------------------------------
     def _latent_hw(self, H, W):
@@ -173,43 +200,72 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         (mpc_rans_encode_laplace: two row entries per symbol) -- the reference materialises all of them
         (abstract_model.py:409-416, 514 bytes per symbol); here the only per-symbol scratch is the coder's 8-byte
         (start, frequency, reciprocal) entry."""
+        job = self.encode_batch_begin(input_image, entropy_coding)
+        if not entropy_coding:
+            self._check_clamped(job)
+            B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
+            return job["sym_y"].view(B, h, w, M).permute(0, 3, 1, 2).reshape(B, -1), job["sym_z"].reshape(B, -1)
+        return self.encode_batch_finish(job)[0]
+
+    def encode_batch_begin(self, input_image, entropy_coding=True, input_nhwc=None):
+        """Enqueues g_a, h_a, the symbols and -- for an entropy-coded call -- h_s and the bit estimate on the current
+        stream, starts the copy of the three numbers the host needs (two clamped counts, the estimate) and returns at
+        once.  -> a job for encode_batch_finish; job["transforms_done"] is an event recorded behind g_a.  input_nhwc:
+        the image already in the first layer's layout (ops.nchw_to_nhwc(x, 4))."""
         self._require_eval()
         x = input_image.contiguous()
         B, _, H, W = x.shape
-        y, yhat = self.Encoder.forward_nhwc(ops.nchw_to_nhwc(x, 4), round_out=True)
+        if entropy_coding and (H % 64 or W % 64):
+            raise ValueError("entropy-coded encode needs H and W to be multiples of 64")
+        x4 = input_nhwc if input_nhwc is not None else ops.nchw_to_nhwc(x, 4)
+        y, yhat = self.Encoder.forward_nhwc(x4, round_out=True)
+        transforms_done = torch.cuda.Event()
+        transforms_done.record()
         _, zhat = self.priorEncoder.forward_nhwc(y, round_out=True)
         sym_y, clamp_y = ops.latent_to_symbols(yhat, self.min_feat_gaussian, self.q_intv, self._main_L() - 1)
         sym_z, clamp_z = ops.latent_to_symbols(zhat, self.min_feat, self.q_intv, self._n_targets() - 1)
-        _, h, w, M = yhat.shape
-        N = self.out_channel_N
-        coded = entropy_coding and not (H % 64 or W % 64)
-        if coded:
+        _, h, w, _ = yhat.shape
+        sigma = None
+        bits = torch.zeros(1, dtype=torch.float64, device=x.device)
+        if entropy_coding:
             self.update_entropy_table()                 # small (N x L); keeps the z table in step with the parameters
             sigma = self.priorDecoder.forward_nhwc(zhat)
             bits = ops.laplace_bits_total(yhat, sigma)
-        else:
-            bits = torch.zeros(1, dtype=torch.float64, device=x.device)
         # one readback for the two clamped counts and the bit estimate the stream count is chosen from
-        n_clamp_y, n_clamp_z, est_bits = torch.cat([clamp_y.view(-1)[:1].double(), clamp_z.view(-1)[:1].double(), bits.view(-1)]).cpu().tolist()
+        numbers = torch.cat([clamp_y.view(-1)[:1].double(), clamp_z.view(-1)[:1].double(), bits.view(-1)])
+        host = self._meta_host(6, "encode").view(torch.float64)
+        host.copy_(numbers, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+        return dict(B=B, H=H, W=W, h=h, w=w, sym_y=sym_y, sym_z=sym_z, sigma=sigma, host=host, ready=ready,
+                    transforms_done=transforms_done, dev=x.device)
+
+    def _check_clamped(self, job):
+        job["ready"].synchronize()
+        n_clamp_y, n_clamp_z, est_bits = job["host"].tolist()
         if n_clamp_y or n_clamp_z:
             raise ValueError("encode: a latent falls outside the CDF tables' range "
                              f"[{self.min_feat_gaussian},{self.max_feat_gaussian}] / [{self.min_feat},{self.max_feat}]")
-        if not entropy_coding:
-            return sym_y.view(B, h, w, M).permute(0, 3, 1, 2).reshape(B, -1), sym_z.reshape(B, -1)
-        if not coded:
-            raise ValueError("entropy-coded encode needs H and W to be multiples of 64")
-        est = est_bits / 8 / B
-        n_loc = h * w
-        main = ops.rans_encode_laplace(sigma, sym_y, B, M, self.min_feat_gaussian - 0.5, self._main_L(), self.precision,
-                                       *ops.choose_streams(n_loc, M, est))
+        return est_bits
+
+    def encode_batch_finish(self, job):
+        """Waits for the job's three numbers, enqueues the two coders with the stream counts chosen from the estimate
+        and brings the byte strings to the host.  -> (list of [main string, z string, H, W],): the arguments of
+        decode_batch_begin.  Call it with the stream the job began on current."""
+        B, H, W, h, w, dev = job["B"], job["H"], job["W"], job["h"], job["w"], job["dev"]
+        N, M = self.out_channel_N, self.out_channel_M
+        est = self._check_clamped(job) / 8 / B
+        sym_z = job["sym_z"]
+        main = ops.rans_encode_laplace(job["sigma"], job["sym_y"], B, M, self.min_feat_gaussian - 0.5, self._main_L(),
+                                       self.precision, *ops.choose_streams(h * w, M, est))
         n_zloc = sym_z.numel() // (B * N)
-        zidx = torch.zeros(B * n_zloc, dtype=torch.int32, device=x.device)
+        zidx = torch.zeros(B * n_zloc, dtype=torch.int32, device=dev)
         # the z string is a hundredth of the image: its streams are budgeted against the image's bytes, not its own
         # (a handful of streams would make its two coders the longest serial chains of the whole codec)
         side = ops.rans_encode(self._z_table(), zidx, sym_z.reshape(-1), B,
                                *ops.choose_streams(n_zloc, N, est + float(n_zloc * N), ops.MRS1_STREAM_BUDGET / 2))
         mains, zstrs = ops.containers_to_bytes([main, side])   # both coders enqueued, then sizes and payloads read back together
-        return [[mains[i], zstrs[i], H, W] for i in range(B)]
+        return ([[mains[i], zstrs[i], H, W] for i in range(B)],)
 
     def encode(self, input_image, entropy_coding=True):
         """One image -> [main string, z string, H, W] (abstract_model.py:370-454); with entropy_coding=False the
@@ -223,6 +279,13 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         """A list of B bitstreams [main string, z string, H, W] of equally sized images -> reconstruction [B, 3, H, W]
         (NCHW, unclamped).  The z strings are decoded first; sigma = h_s(z_hat) then gives the decoder of the main
         strings its rows (mpc_rans_decode_laplace), exactly as the encoder saw them."""
+        job = self.decode_batch_begin(bitstreams)
+        self.decode_batch_synthesis(job)
+        return self.decode_batch_finish(job)
+
+    def decode_batch_begin(self, bitstreams):
+        """Copies the strings to the device and enqueues both decoders (with h_s between them) on the current stream.
+        -> a job for decode_batch_synthesis (enqueues g_s) and decode_batch_finish (checks the decoders' status)."""
         self._require_eval()
         B = len(bitstreams)
         if B == 0:
@@ -250,11 +313,33 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         # so the two statuses are read back together, once, before the result is used)
         sym_y, ystatus = ops.rans_decode_laplace(sigma, ydata, ynb, B, M, self.min_feat_gaussian - 0.5, self._main_L(),
                                                  self.precision, *y_geometry)
-        status = torch.cat([zstatus, ystatus]).cpu().tolist()
+        st_host = self._meta_host(2 * B, "decode")
+        st_host.copy_(torch.cat([zstatus, ystatus]), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return dict(B=B, h=h, w=w, sym=sym_y, st_host=st_host, done=done, recon=None, keep=(zdata, ydata, sigma))
+
+    def decode_batch_synthesis(self, job, score_against=None, events=None):
+        """Enqueues g_s for a job of decode_batch_begin (on the stream that job began on).  score_against (the
+        batch's original, NCHW fp32): the job's reconstruction is then clamp(x_hat, 0, 1) and job["sse"] holds the
+        per-image squared errors against it.  events: passed to the synthesis network (see Synthesis_net.forward_nhwc)."""
+        B, h, w, M = job["B"], job["h"], job["w"], self.out_channel_M
+        yhat = ops.symbols_to_latent(job["sym"].view(B, h, w, M), self.min_feat_gaussian, self.q_intv)
+        kw = dict(events=events) if events is not None else {}
+        if score_against is None:
+            job["recon"] = self.Decoder.forward_nhwc(yhat, **kw)
+        else:
+            job["recon"], job["sse"] = self.Decoder.forward_nhwc(yhat, score_against=score_against, **kw)
+        return job
+
+    def decode_batch_finish(self, job):
+        """Waits for the job's decoders (not for g_s), checks their status, returns the reconstruction."""
+        job["done"].synchronize()
+        B = job["B"]
+        status = job["st_host"].tolist()
         if min(status) < 0:
             raise _lib.MpcError(f"corrupt MRS1 stream: decoder status z {status[:B]}, main {status[B:]}")
-        yhat = ops.symbols_to_latent(sym_y.view(B, h, w, M), self.min_feat_gaussian, self.q_intv)
-        return self.Decoder.forward_nhwc(yhat)
+        return job["recon"]
 
     def decode(self, bitstream):
         """[main string, z string, H, W] -> reconstruction (NCHW, unclamped); a tensor is taken as the latent and

@@ -322,25 +322,6 @@ class Balle2017ManyPriors_ImageCompressor(abstract_model.AbstractHyperpriorImage
         host = stage.numpy()
         return [host[i, :nb[i]].tobytes() for i in range(n_images)], (n_streams, lps)
 
-    def _staging(self, nbytes, purpose="bytes"):
-        """Page-locked host buffer of at least nbytes (uint8), reused between calls.  One buffer per purpose and per HIP
-        stream: calls that are in flight on different streams (CodecPipeline) never share one."""
-        bufs = self.__dict__.setdefault("_stage_bufs", {})
-        key = (purpose, torch.cuda.current_stream().cuda_stream)
-        buf = bufs.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        return buf
-
-    def _meta_host(self, n, purpose="meta"):
-        """Page-locked int32 host buffer for the one small readback of a call (per purpose and stream, as above)."""
-        bufs = self.__dict__.setdefault("_meta_bufs", {})
-        key = (purpose, torch.cuda.current_stream().cuda_stream)
-        buf = bufs.get(key)
-        if buf is None or buf.numel() < n:
-            buf = bufs[key] = torch.empty(max(n, 256), dtype=torch.int32, pin_memory=True)
-        return buf[:n]
-
     def encode_batch(self, input_image, entropy_coding=True):
         """Batched encode: -> (list of byte strings | int16 symbols [B, h*w*M], idx int32 [B, h*w], h, w).
 

@@ -24,6 +24,12 @@ registers fit a SIMD, and alone each kernel keeps the matrix pipe under half bus
 2.55 ms instead of 1.43 + 1.24 ms one after the other, and the decoder, which loses its place beside the first
 layer, costs the second layer 0.28 ms: 1.3-2.5 % slower over the whole step, hence off by default.
 
+The driver works with any model that splits its codec into encode_batch_begin / encode_batch_finish (-> a tuple: the
+byte strings first, the whole tuple being the arguments of) decode_batch_begin / decode_batch_synthesis /
+decode_batch_finish: the Manypriors models (one string per image, coded under the winning prior's table) and the
+hyperprior models (two strings per image; their encode_batch_finish also enqueues the two coders, which then run beside
+the next batch's g_a).
+
 The reference codes one image at a time on one stream (src/compression/tests.py:439-460); it has no counterpart of
 this driver.
 """
@@ -58,12 +64,13 @@ class CodecPipeline:
 
     def _decode(self, undecoded, transforms_done):
         """Enqueues decoder and g_s of the batch whose byte strings are on the host, each behind its event."""
-        strings, idx, h, w, stream, tag, target = undecoded
+        coded, stream, tag, target = undecoded                  # coded: what encode_batch_finish returned, strings first
+        strings = coded[0]
         with torch.cuda.stream(stream):
             held_by = self.synthesis_done if self.decoder_behind == "synthesis" else self.deconv2_done
             if held_by is not None:
                 stream.wait_event(held_by)
-            job = self.model.decode_batch_begin(strings, idx, h, w)
+            job = self.model.decode_batch_begin(*coded)
             if transforms_done is not None:
                 stream.wait_event(transforms_done)               # g_s(n-1) behind the third layer of g_a(n)
             events = {}
@@ -78,8 +85,8 @@ class CodecPipeline:
         enc, stream, tag, target = self.encoding
         self.encoding = None
         with torch.cuda.stream(stream):
-            strings, idx, h, w = self.model.encode_batch_finish(enc)
-        return self._decode((strings, idx, h, w, stream, tag, target), transforms_done)
+            coded = self.model.encode_batch_finish(enc)
+        return self._decode((coded, stream, tag, target), transforms_done)
 
     def submit(self, x, tag=None, target=None):
         """Enqueues the encoder of batch n, then fetches the byte strings of batch n - 1 and enqueues its decoder and
@@ -94,7 +101,7 @@ class CodecPipeline:
         with torch.cuda.stream(self.early):
             x4 = ops.nchw_to_nhwc(x.contiguous(), 4)
         with torch.cuda.stream(stream):
-            if self.early_first_layer:
+            if self.early_first_layer:                         # (the Manypriors models' encode_batch_begin only)
                 enc = self.model.encode_batch_begin(x, input_nhwc=x4, first_layer_on=(self.early, self.deconv2_done))
             else:
                 stream.wait_stream(self.early)

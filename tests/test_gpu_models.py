@@ -362,6 +362,43 @@ def test_testolina_hyperprior_codec_round_trip(dev):
     assert (recon.clamp(0, 1) - out["reconstructed_image"]).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("arch", ["TestolinaHP", "Balle2018PTTFExp"])
+def test_codec_pipeline_with_a_hyperprior_model(dev, arch):
+    """CodecPipeline over a hyperprior model (two strings per image; the coders are enqueued by encode_batch_finish and
+    run beside the next batch's g_a): batch for batch the byte strings and the reconstruction of encode_batch ->
+    decode_batch run one after the other, the fused score of the last layer included, twice over the same buffers."""
+    import compression_amd as ca
+    from compression_amd import ops
+    from compression_amd.pipeline import CodecPipeline
+    sdh = synth.transform_weights(237, N, M, testolina=arch.startswith("Testolina"))
+    sdh.update(synth.hyperprior_weights(239, N, M))
+    m = ca.init_model(arch, dev, out_channel_N=N, out_channel_M=M)
+    m.load_state_dict(sdh)
+    m.eval()
+    batches = [synth.smooth_image(500 + i, 4, 256, 384).to(dev) for i in range(4)]
+    want = []
+    for x in batches:
+        streams = m.encode_batch(x)
+        want.append((streams, m.decode_batch(streams).clone()))
+    torch.cuda.synchronize()
+    pipe = CodecPipeline(m, dev, after_synthesis=lambda job, strings, tag: job["sse"])
+    got = []
+    for rep in range(2):
+        for i, x in enumerate(batches):
+            r = pipe.submit(x, tag=i, target=x)
+            if r is not None:
+                got.append(r)
+        got.append(pipe.flush())
+        pipe.synchronize()
+    assert [g[3] for g in got] == [0, 1, 2, 3] * 2
+    for strings, recon, sse, tag in got:
+        assert strings == want[tag][0], f"batch {tag}: byte strings differ"
+        ref_xhat, ref_sse = ops.clamp_sse_per_image(want[tag][1], batches[tag])
+        assert torch.equal(recon, ref_xhat), f"batch {tag}: reconstruction differs"
+        assert torch.allclose(sse, ref_sse, rtol=1e-12, atol=0.0)
+    assert pipe.flush() is None
+
+
 def _lib_error():
     from compression_amd import MpcError
     return (MpcError, ValueError)

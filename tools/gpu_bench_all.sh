@@ -8,4 +8,5 @@ PY
 }
 run config3 && run config3_serial --serial --no-cpu-baseline && run config3_smooth --data smooth --no-cpu-baseline && run config1 --config 1 --no-cpu-baseline --steps 50 && run config2 --config 2 --no-cpu-baseline --steps 50 \
  && run config4 --config 4 --no-cpu-baseline && run config5 --config 5 --no-cpu-baseline && run config5_testolina --config 5 --arch TestolinaManyPriors --no-cpu-baseline \
- && run config6_hyperprior --config 6 --steps 10 && run config6_balle2018 --config 6 --arch Balle2018PTTFExp --steps 10
+ && run config6_hyperprior --config 6 --steps 20 --no-cpu-baseline && run config6_hyperprior_serial --config 6 --steps 10 --serial --no-cpu-baseline \
+ && run config6_balle2018 --config 6 --arch Balle2018PTTFExp --steps 20 --no-cpu-baseline
