@@ -335,6 +335,8 @@ struct mpc_conv {
     int sy, sx, my, mx;
     Phase ph[MAX_PHASES];
     void *wpk = nullptr;
+    void *wpk_narrow = nullptr;      // exact f32 layers without GDN: the same weights packed as one group per 32 output channels
+    int64_t w_group_narrow = 0;      // (for launches whose pixels do not fill the GPU, see conv_igemm.hip)
     float *bias = nullptr, *beta = nullptr;   // bias: nf*groups*32 floats, followed by 64 floats of zeros
     void *gamma = nullptr;
     int2 *taps = nullptr;

@@ -465,6 +465,11 @@ __global__ void gdn_reparam_kernel(const float *__restrict__ x, int64_t n, float
 
 namespace {
 
+#ifndef MPC_NARROW_BELOW
+#define MPC_NARROW_BELOW 256
+#endif
+constexpr int MPC_NARROW_BELOW_WORKGROUPS = MPC_NARROW_BELOW;     // fewer workgroups than CUs: split the output channels over more of them
+
 template <int NF, bool CIN4, int EPI>
 int launch(mpc_ctx *ctx, const Params &p, int nphase, int groups) {
     size_t lds = (size_t)2 * NF * 32 * 32 * sizeof(float);
@@ -617,6 +622,24 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
         pack_weights_kernel<<<dim3((unsigned)mpc_cdiv(w_total, 256)), dim3(256), 0, ctx->stream>>>(pd, weight, c->wpk, w_total);
     }
     if ((e = hipGetLastError()) != hipSuccess) return fail("pack_weights launch");
+    if (!f16 && !x3 && !cin4 && !stacked && !gdn && tiles > 1) {
+        // The same weights once more with ONE 32-channel tile per cout group.  A workgroup's time is its K loop, nf
+        // tiles wide, however few pixels the launch has; a launch of fewer workgroups than the GPU has CUs (the
+        // hyperprior networks work on 1/64 .. 1/1024 of the image's pixels) runs its groups side by side instead:
+        // nf times the workgroups, each 1/nf as long.  Every output channel is summed in the same order either way.
+        PackDesc pn = pd;
+        pn.cout_pad = 32;
+        int64_t group_total = 0;
+        for (int ph = 0; ph < pn.nphase; ++ph) {
+            pn.w_off[ph] = group_total;
+            group_total += (int64_t)pn.nchunks[ph] * 32 * 32;
+        }
+        pn.w_group = c->w_group_narrow = group_total;
+        const int64_t narrow_total = group_total * tiles;
+        if ((e = hipMalloc((void **)&c->wpk_narrow, sizeof(float) * narrow_total)) != hipSuccess) return fail("hipMalloc(narrow weights)");
+        pack_weights_kernel<<<dim3((unsigned)mpc_cdiv(narrow_total, 256)), dim3(256), 0, ctx->stream>>>(pn, weight, c->wpk_narrow, narrow_total);
+        if ((e = hipGetLastError()) != hipSuccess) return fail("pack_weights launch (narrow)");
+    }
     if (f16 && stacked && mpc_conv_rgb16_supported(d.cin, d.cout)) {
         if ((e = hipMalloc(&c->wpk_rgb16, mpc_conv_rgb16_image_bytes(d.cin))) != hipSuccess) return fail("hipMalloc(rgb16 weights)");
         if ((e = mpc_conv_rgb16_pack(weight, d.cin, d.cout, c->wpk_rgb16, ctx->stream)) != hipSuccess) return fail("pack_rgb16 launch");
@@ -675,7 +698,7 @@ int mpc_conv_create(mpc_ctx *ctx, const mpc_conv_desc *desc, const float *weight
 int mpc_conv_destroy(mpc_conv *c) {
     if (!c) return MPC_OK;
     mpc_device_guard guard(c->device);
-    (void)hipFree(c->wpk); (void)hipFree(c->bias); (void)hipFree(c->beta); (void)hipFree(c->gamma); (void)hipFree(c->taps);
+    (void)hipFree(c->wpk); (void)hipFree(c->wpk_narrow); (void)hipFree(c->bias); (void)hipFree(c->beta); (void)hipFree(c->gamma); (void)hipFree(c->taps);
     (void)hipFree(c->gamma_x3);
     (void)hipFree(c->wpk_rgb16);
     delete c;
@@ -765,6 +788,13 @@ static int conv_forward_impl(mpc_ctx *ctx, const mpc_conv *c, const void *in, in
             if (c->nf == 6) return launch<6, false, EPI_GDN>(ctx, p, np, ng);
         }
     } else if (!c->cin4) {
+        if (c->wpk_narrow && mpc_cdiv(p.P, PIX_PER_BLOCK) * np * ng < MPC_NARROW_BELOW_WORKGROUPS) {
+            Params pn = p;                                     // one 32-channel tile per group (see mpc_conv_create)
+            pn.wpk = c->wpk_narrow;
+            pn.w_group = c->w_group_narrow;
+            for (int i = 0; i < np; ++i) pn.ph[i].w_off = p.ph[i].w_off / c->nf;
+            return launch<1, false, EPI_PLAIN>(ctx, pn, np, c->nf * ng);
+        }
         if (c->nf == 4) return launch<4, false, EPI_PLAIN>(ctx, p, np, ng);
         if (c->nf == 5) return launch<5, false, EPI_PLAIN>(ctx, p, np, ng);
         if (c->nf == 6) return launch<6, false, EPI_PLAIN>(ctx, p, np, ng);

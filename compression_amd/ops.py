@@ -702,6 +702,9 @@ class ConvLayer:
             self._name_fmt = "deconv5s2_patch_f16_kernel<%d, %d>" % (nf, epi)
         self._launches = (tiles // nf) * (4 if (kind == _lib.MPC_DECONV and stride == 2 and not self.small_cout) else 1)
         self.kernel_name = self._name_fmt if (self._patch or not (x3 or f16)) else self._name_fmt % 4
+        # exact f32 layers without GDN run one 32-channel tile per workgroup group when the launch has fewer workgroups
+        # than the GPU has CUs (the library's rule, mirrored for the kernel name in profiles)
+        self._narrow_ok = not (x3 or f16 or gdn or self.small_cout) and cin > 4 and tiles > 1
         # the fp16 last layer (cout <= 4) has a kernel of its own
         self._rgb16 = f16 and self.small_cout and cout <= 4 and cin % 64 == 0 and cin <= 256
         ctx = context_for(w.device)
@@ -745,6 +748,9 @@ class ConvLayer:
             base = B * (H * W if self.kind == _lib.MPC_DECONV else Ho * Wo)
             wide = (wide_block or -(-base // 256) * self._launches >= 512) and not self.small_cout
             self.kernel_name = "deconv_rgb16_kernel" if self._rgb16 else self._name_fmt if self._patch else self._name_fmt % (8 if wide else 4)
+        elif self._narrow_ok:
+            base = B * (H * W if self.kind == _lib.MPC_DECONV else Ho * Wo)
+            self.kernel_name = "conv_igemm_kernel<1, false, 0>" if -(-base // 128) * self._launches < 256 else self._name_fmt
         if out_split:
             shape, odt = (B, Ho, Wo, self.cout // 8, 16), torch.float16
         else:
