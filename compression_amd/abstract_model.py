@@ -113,11 +113,6 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         if authority not in ("device", "host"):
             raise ValueError(f"table authority must be 'device' or 'host', got {authority!r}")
         L = self._n_targets()
-        # Built again only when the prior's parameters (or what the table is made with) have changed: the codec calls
-        # this before every batch, and batches that are in flight on different streams share the table.
-        made_from = (authority, L, self.min_feat, self.max_feat, self.precision, tuple((p.data_ptr(), p._version) for p in self.bitEstimator_z.parameters()))
-        if getattr(self, "_z_table_made_from", None) == made_from:
-            return True
         if authority == "host":
             dev = next(self.bitEstimator_z.parameters()).device
             tf = self.bitEstimator_z.table_host(self.min_feat - 0.5, self.max_feat + 0.5, L).to(dev)
@@ -129,8 +124,20 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         self.z_entropy_table = _renorm_cast_cdf_(tf, self.precision)
         if tf.is_cuda:
             torch.cuda.current_stream(tf.device).synchronize()                  # complete before any other stream reads it
-        object.__setattr__(self, "_z_table_made_from", made_from)
+        object.__setattr__(self, "_z_table_made_from", self._z_table_inputs(authority))
         return True
+
+    def _z_table_inputs(self, authority=None):
+        return (authority or self.table_authority, self._n_targets(), self.min_feat, self.max_feat, self.precision,
+                tuple((p.data_ptr(), p._version) for p in self.bitEstimator_z.parameters()))
+
+    def _ensure_z_table(self):
+        """The codec's own call before every batch: builds the z table again only when the prior's parameters (or what
+        the table is made with) have changed since it was built -- batches that are in flight on different streams
+        share the table.  (In-place changes are seen through the parameters' version counters; after writing through
+        `.data`, call update_entropy_table() or eval().)"""
+        if getattr(self, "_z_table_made_from", None) != self._z_table_inputs():
+            self.update_entropy_table()
 
     def eval(self):
         if self.entropy_coding and next(self.parameters()).is_cuda:
@@ -228,7 +235,7 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         sigma = None
         bits = torch.zeros(1, dtype=torch.float64, device=x.device)
         if entropy_coding:
-            self.update_entropy_table()                 # small (N x L); keeps the z table in step with the parameters
+            self._ensure_z_table()                      # small (N x L); keeps the z table in step with the parameters
             sigma = self.priorDecoder.forward_nhwc(zhat)
             bits = ops.laplace_bits_total(yhat, sigma)
         # one readback for the two clamped counts and the bit estimate the stream count is chosen from
@@ -296,7 +303,7 @@ class AbstractHyperpriorImageCompressor(AbstractImageCompressor):
         if H % 64 or W % 64:
             raise ValueError("decode needs H and W to be multiples of 64")
         dev = next(self.parameters()).device
-        self.update_entropy_table()
+        self._ensure_z_table()
         (h, w), (zh, zw) = self._latent_hw(H, W)
         N, M = self.out_channel_N, self.out_channel_M
         zidx = torch.zeros(B * zh * zw, dtype=torch.int32, device=dev)
